@@ -1,0 +1,173 @@
+// extern "C" entry points of libdiner_hip.so (declared in include/diner_hip.h): argument
+// validation, error strings, stream plumbing.  No kernel code here.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "common.hpp"
+
+namespace diner {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int check_launch(const char *what)
+{
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_error("%s: %s", what, hipGetErrorString(e));
+        return DINER_E_LAUNCH;
+    }
+    return DINER_OK;
+}
+
+int launch_composite(const float *, const float *, const float *, int64_t, int, int, float *, float *, float *, hipStream_t);
+int launch_pack_maps(const float *, const float *, const float *, int64_t, int, int, float *, hipStream_t);
+int launch_pack_latent(const float *, int64_t, int, int, int, float *, hipStream_t);
+int launch_pack_mlp(const DinerMlpRaw &, float *, hipStream_t);
+int64_t mlp_packed_floats();
+int launch_sampler(const DinerScene &, const float *, int64_t, const DinerSamplerCfg &, const float *, const float *,
+                   const float *, const float *, uint64_t, float *, float *, float *, hipStream_t);
+int launch_sample_coarse(const float *, int64_t, int, const float *, uint64_t, float *, hipStream_t);
+int launch_fill_up(const float *, const float *, int64_t, int, const float *, uint64_t, float *, hipStream_t);
+int launch_points_mlp(const DinerScene &, const float *, const float *, const float *, int64_t, int, float *, hipStream_t);
+
+static int bad(const char *msg)
+{
+    set_error("%s", msg);
+    return DINER_E_INVALID;
+}
+
+static int check_scene(const DinerScene *s, bool need_latent)
+{
+    if (!s) return bad("scene is NULL");
+    if (s->SB < 0 || s->NV <= 0 || s->H <= 0 || s->W <= 0) return bad("scene: bad SB/NV/H/W");
+    if (!s->poses || !s->focal || !s->c || !s->maps) return bad("scene: NULL camera or map pointer");
+    if (!(s->image_w > 0.f) || !(s->image_h > 0.f)) return bad("scene: bad image_shape");
+    if (need_latent) {
+        if (!s->latent) return bad("scene: latent is NULL");
+        if (s->h <= 0 || s->w <= 0) return bad("scene: bad latent size");
+    }
+    return DINER_OK;
+}
+
+static int check_cfg(const DinerSamplerCfg *c)
+{
+    if (!c) return bad("sampler cfg is NULL");
+    if (c->n_candidates < 1) return bad("n_candidates must be >= 1");
+    if (c->n_samples < 1 || c->n_samples > 8192) return bad("n_samples must be in [1, 8192]");
+    if (c->n_gaussian < 0 || c->n_gaussian > c->n_samples) return bad("need 0 <= n_gaussian <= n_samples");  // nerf_renderer.py:89
+    return DINER_OK;
+}
+
+}  // namespace diner
+
+using namespace diner;
+
+extern "C" {
+
+const char *diner_last_error(void) { return g_err; }
+int diner_version(void) { return 1; }
+
+int diner_pack_maps(const float *depths, const float *depths_std, const float *normals, int64_t N, int32_t H,
+                    int32_t W, float *maps_out, void *stream)
+{
+    if (!depths || !depths_std || !normals || !maps_out) return bad("pack_maps: NULL pointer");
+    if (N < 0 || H <= 0 || W <= 0) return bad("pack_maps: bad size");
+    return launch_pack_maps(depths, depths_std, normals, N, H, W, maps_out, (hipStream_t)stream);
+}
+
+int diner_pack_latent(const float *latent_nchw, int64_t N, int32_t C, int32_t h, int32_t w, float *latent_out,
+                      void *stream)
+{
+    if (!latent_nchw || !latent_out) return bad("pack_latent: NULL pointer");
+    if (N < 0 || h <= 0 || w <= 0) return bad("pack_latent: bad size");
+    return launch_pack_latent(latent_nchw, N, C, h, w, latent_out, (hipStream_t)stream);
+}
+
+int64_t diner_mlp_packed_floats(void) { return mlp_packed_floats(); }
+
+int diner_pack_mlp(const DinerMlpRaw *raw, float *packed_out, void *stream)
+{
+    if (!raw || !packed_out) return bad("pack_mlp: NULL pointer");
+    const float *const *p = (const float *const *)raw;
+    for (size_t i = 0; i < sizeof(DinerMlpRaw) / sizeof(float *); ++i)
+        if (!p[i]) return bad("pack_mlp: NULL weight pointer");
+    return launch_pack_mlp(*raw, packed_out, (hipStream_t)stream);
+}
+
+int diner_sample_coarse(const float *rays, int64_t N, int32_t NC, const float *u_coarse, uint64_t seed, float *z_out,
+                        void *stream)
+{
+    if (N < 0 || NC < 1) return bad("sample_coarse: bad N / NC");
+    if (N > 0 && (!rays || !z_out)) return bad("sample_coarse: NULL pointer");
+    return launch_sample_coarse(rays, N, NC, u_coarse, seed, z_out, (hipStream_t)stream);
+}
+
+int diner_fill_up_uniform_samples(const float *rays, const float *z_in, int64_t N, int32_t K, const float *u_fill,
+                                  uint64_t seed, float *z_out, void *stream)
+{
+    if (N < 0 || K < 1 || K > 8192) return bad("fill_up: bad N / K");
+    if (N > 0 && (!rays || !z_in || !z_out)) return bad("fill_up: NULL pointer");
+    return launch_fill_up(rays, z_in, N, K, u_fill, seed, z_out, (hipStream_t)stream);
+}
+
+int diner_sample_depthguided(const DinerScene *scene, const float *rays, int64_t NR, const DinerSamplerCfg *cfg,
+                             const float *u_coarse, const float *n_gauss, const float *u_fill, const float *z_cand,
+                             uint64_t seed, float *z_out, float *z_dg_out, float *lik_out, void *stream)
+{
+    int rc;
+    if ((rc = check_scene(scene, false)) || (rc = check_cfg(cfg))) return rc;
+    if (NR < 0) return bad("NR < 0");
+    if (NR > 0 && scene->SB > 0 && (!rays || !z_out)) return bad("sample_depthguided: NULL rays / z_out");
+    return launch_sampler(*scene, rays, NR, *cfg, u_coarse, n_gauss, u_fill, z_cand, seed, z_out, z_dg_out, lik_out,
+                          (hipStream_t)stream);
+}
+
+int diner_render_points(const DinerScene *scene, const float *mlp_packed, const float *rays, const float *z,
+                        int64_t NR, int32_t K, float *rgbsigma_out, void *stream)
+{
+    int rc;
+    if ((rc = check_scene(scene, true))) return rc;
+    if (NR < 0 || K < 1) return bad("render_points: bad NR / K");
+    if (!mlp_packed) return bad("render_points: mlp_packed is NULL");
+    if (NR > 0 && scene->SB > 0 && (!rays || !z || !rgbsigma_out)) return bad("render_points: NULL rays / z / out");
+    return launch_points_mlp(*scene, mlp_packed, rays, z, NR, K, rgbsigma_out, (hipStream_t)stream);
+}
+
+int diner_composite(const float *rays, const float *z, const float *rgbsigma, int64_t N, int32_t K,
+                    int32_t white_bkgd, float *rgb_out, float *depth_out, float *weights_out, void *stream)
+{
+    if (N < 0 || K < 1) return bad("composite: bad N / K");
+    if (N > 0 && (!rays || !z || !rgbsigma || !rgb_out || !depth_out)) return bad("composite: NULL pointer");
+    return launch_composite(rays, z, rgbsigma, N, K, white_bkgd, rgb_out, depth_out, weights_out, (hipStream_t)stream);
+}
+
+int64_t diner_render_workspace_floats(int64_t SB, int64_t NR, int32_t K) { return SB * NR * (int64_t)K * 5; }
+
+int diner_render(const DinerScene *scene, const float *mlp_packed, const float *rays, int64_t NR,
+                 const DinerSamplerCfg *cfg, int32_t white_bkgd, const float *u_coarse, const float *n_gauss,
+                 const float *u_fill, uint64_t seed, float *workspace, float *rgb_out, float *depth_out,
+                 float *weights_out, void *stream)
+{
+    int rc;
+    if ((rc = check_scene(scene, true)) || (rc = check_cfg(cfg))) return rc;
+    if (NR < 0) return bad("NR < 0");
+    if (NR == 0 || scene->SB == 0) return DINER_OK;
+    if (!workspace) return bad("render: workspace is NULL");
+    const int64_t N = (int64_t)scene->SB * NR;
+    float *z = workspace, *rgbsigma = workspace + N * cfg->n_samples;
+    if ((rc = diner_sample_depthguided(scene, rays, NR, cfg, u_coarse, n_gauss, u_fill, nullptr, seed, z, nullptr,
+                                       nullptr, stream)))
+        return rc;
+    if ((rc = diner_render_points(scene, mlp_packed, rays, z, NR, cfg->n_samples, rgbsigma, stream))) return rc;
+    return diner_composite(rays, z, rgbsigma, N, cfg->n_samples, white_bkgd, rgb_out, depth_out, weights_out, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,338 @@
+"""``NeRFRendererDGS`` -- the MI355X-native drop-in for the reference renderer plug-in.
+
+Mirrors ``src/models/nerf_renderer.py:12-430`` of tancredeguillou/diner: same constructor
+kwargs, same mutable attributes (``n_samples``/``n_gaussian`` are re-assigned after loading a
+checkpoint, ``python_scripts/create_prediction_folder.py:49-52``), same
+``forward(model, rays, want_weights)`` contract and the same stage methods.  Selecting it is a
+one-line YAML change (``renderer.module: diner_amd.NeRFRendererDGS``, resolved by
+``src/util/import_helper.py:16-24`` at ``src/models/diner.py:48``).
+
+All arithmetic runs in the hand-written HIP kernels of ``libdiner_hip.so`` through the C ABI in
+``include/diner_hip.h``; PyTorch only owns device memory and the stream.  There is no CPU or
+eager fallback: without the library the import of this module's dependencies fails.
+
+The module holds no parameters or buffers (reference checkpoints load with ``strict=True``); it
+keeps an identity-keyed cache of re-packed copies of the model's maps and MLP weights
+(invalidated when a tensor's ``data_ptr``/``_version``/shape changes).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import DinerMlpRaw, DinerSamplerCfg, DinerScene, check
+
+
+class RenderOutput(dict):
+    """Attribute dict standing in for ``dotmap.DotMap`` (reference nerf_renderer.py:421-430)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def _sig(t: torch.Tensor):
+    return (t.data_ptr(), t._version, tuple(t.shape), t.dtype, str(t.device))
+
+
+def _f32c(t: torch.Tensor) -> torch.Tensor:
+    return t.detach().to(torch.float32).contiguous()
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream(device) -> C.c_void_p:
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class NeRFRendererDGS(torch.nn.Module):
+    """NeRF renderer with depth-guided sampling (reference nerf_renderer.py:12-37).
+
+    :param n_samples: samples per ray
+    :param n_depth_candidates: stratified candidates that are short-listed by surface likelihood
+    :param n_gaussian: samples drawn from the gaussian fitted to the occlusion-aware likelihoods
+    :param eval_batch_size: kept for signature compatibility (the fused kernel needs no chunking)
+    :param white_bkgd: white instead of black background
+    """
+
+    def __init__(self, n_samples=40, n_depth_candidates=1000, n_gaussian=15, eval_batch_size=100000,
+                 white_bkgd=True):
+        super().__init__()
+        self.n_samples = n_samples
+        self.n_depth_candidates = n_depth_candidates
+        self.n_gaussian = n_gaussian
+        self.eval_batch_size = eval_batch_size
+        self.white_bkgd = white_bkgd
+        self.seed = 0            # base seed of the in-kernel Philox generator (perf mode)
+        self._calls = 0
+        self._maps_key = self._maps_pack = None      # packed depth/sigma/normal maps + cameras
+        self._latent_key = self._latent_pack = None  # packed NHWC latent
+        self._mlp_key = None
+        self._mlp_pack = None
+
+    # ------------------------------------------------------------------------------------------
+    # model -> packed device state (cached)
+    # ------------------------------------------------------------------------------------------
+    @staticmethod
+    def _validate_model(model):
+        enc, mlp = model.encoder, model.mlp_fine
+        if getattr(enc, "index_interp", "bilinear") != "bilinear" or getattr(enc, "index_padding", "border") != "border":
+            raise NotImplementedError("only index_interp='bilinear', index_padding='border' (image_encoder.py:24-25)")
+        if getattr(mlp, "combine_type", "average") != "average":
+            raise NotImplementedError("only combine_type='average' (resnetfc.py:9-14)")
+        if not isinstance(getattr(mlp, "activation", torch.nn.ReLU()), torch.nn.ReLU):
+            raise NotImplementedError("only ReLU activations (beta=0, resnetfc.py:124-127)")
+        dims = (mlp.d_in, mlp.d_latent, mlp.d_hidden, mlp.d_out, mlp.n_blocks, mlp.combine_layer)
+        if dims != (55, 512, 512, 4, 5, 3):
+            raise NotImplementedError(f"fusion MLP dims {dims} unsupported; kernels are built for (55,512,512,4,5,3)")
+        for pe in (model.poscode, model.depthcode):
+            if pe.num_freqs != 6 or not pe.include_input:
+                raise NotImplementedError("positional encoding must be num_freqs=6, include_input=True")
+
+    def _scene(self, model, need_latent=True) -> Tuple[DinerScene, tuple]:
+        enc = model.encoder
+        dev = enc.depths.device
+        mkey = tuple(_sig(t) for t in (model.poses, model.focal, model.c, model.image_shape, enc.depths,
+                                       enc.depths_std, enc.normals))
+        if mkey != self._maps_key:
+            SB, NV, _, H, W = enc.depths.shape
+            maps = torch.empty((SB, NV, H, W, 8), dtype=torch.float32, device=dev)
+            d, s, n = _f32c(enc.depths), _f32c(enc.depths_std), _f32c(enc.normals)
+            check(_lib.lib().diner_pack_maps(_ptr(d), _ptr(s), _ptr(n), SB * NV, H, W, _ptr(maps), _stream(dev)),
+                  "diner_pack_maps")
+            poses = _f32c(model.poses)
+            if poses.shape[-2:] != (4, 4):  # accept [.., 3, 4] poses
+                full = torch.zeros((*poses.shape[:-2], 4, 4), dtype=torch.float32, device=dev)
+                full[..., :3, :] = poses[..., :3, :]
+                full[..., 3, 3] = 1
+                poses = full.contiguous()
+            torch.cuda.current_stream(dev).synchronize()  # d/s/n may be temporaries
+            ishape = [float(v) for v in model.image_shape.detach().float().cpu()]  # (W, H), pixelnerf.py:50-51
+            self._maps_pack, self._maps_key = (maps, poses, _f32c(model.focal), _f32c(model.c), ishape), mkey
+        if need_latent:
+            lkey = _sig(enc.latent)
+            if lkey != self._latent_key:
+                lat = _f32c(enc.latent)
+                SB, NV, Cc, h, w = lat.shape
+                latent = torch.empty((SB, NV, h, w, Cc), dtype=torch.float32, device=dev)
+                check(_lib.lib().diner_pack_latent(_ptr(lat), SB * NV, Cc, h, w, _ptr(latent), _stream(dev)),
+                      "diner_pack_latent")
+                torch.cuda.current_stream(dev).synchronize()
+                self._latent_pack, self._latent_key = latent, lkey
+        maps, poses, focal, c, ishape = self._maps_pack
+        latent = self._latent_pack if need_latent else None
+        SB, NV, H, W, _ = maps.shape
+        sc = DinerScene()
+        sc.SB, sc.NV, sc.H, sc.W = SB, NV, H, W
+        if latent is not None:
+            assert latent.shape[:2] == (SB, NV)  # image_encoder.py:105
+            sc.h, sc.w, sc.C = latent.shape[2], latent.shape[3], latent.shape[4]
+        sc.image_w, sc.image_h = ishape
+        sc.feature_padding = float(model.encoder.feature_padding)
+        sc.num_freqs = int(model.poscode.num_freqs)
+        sc.freq_factor = float(model.poscode.freqs[0])
+        sc.poses, sc.focal, sc.c = poses.data_ptr(), focal.data_ptr(), c.data_ptr()
+        sc.maps = maps.data_ptr()
+        sc.latent = latent.data_ptr() if latent is not None else None
+        return sc, (maps, poses, focal, c, latent)
+
+    def _mlp(self, model) -> torch.Tensor:
+        mlp = model.mlp_fine
+        params = [mlp.lin_in.weight, mlp.lin_in.bias, mlp.lin_out.weight, mlp.lin_out.bias]
+        for b in range(3):
+            params += [mlp.lin_z[b].weight, mlp.lin_z[b].bias]
+        for b in range(5):
+            params += [mlp.blocks[b].fc_0.weight, mlp.blocks[b].fc_0.bias, mlp.blocks[b].fc_1.weight, mlp.blocks[b].fc_1.bias]
+        key = tuple(_sig(p) for p in params)
+        if key != self._mlp_key:
+            keep = [_f32c(p) for p in params]
+            raw = DinerMlpRaw()
+            raw.lin_in_w, raw.lin_in_b, raw.lin_out_w, raw.lin_out_b = [t.data_ptr() for t in keep[:4]]
+            for b in range(3):
+                raw.lin_z_w[b], raw.lin_z_b[b] = keep[4 + 2 * b].data_ptr(), keep[5 + 2 * b].data_ptr()
+            for b in range(5):
+                o = 10 + 4 * b
+                raw.fc0_w[b], raw.fc0_b[b] = keep[o].data_ptr(), keep[o + 1].data_ptr()
+                raw.fc1_w[b], raw.fc1_b[b] = keep[o + 2].data_ptr(), keep[o + 3].data_ptr()
+            dev = keep[0].device
+            packed = torch.empty(int(_lib.lib().diner_mlp_packed_floats()), dtype=torch.float32, device=dev)
+            check(_lib.lib().diner_pack_mlp(C.byref(raw), _ptr(packed), _stream(dev)), "diner_pack_mlp")
+            torch.cuda.current_stream(dev).synchronize()  # `keep` may be temporaries: finish before they die
+            self._mlp_pack, self._mlp_key = packed, key
+        return self._mlp_pack
+
+    @staticmethod
+    def _check_rays(rays):
+        assert len(rays.shape) == 3 and rays.shape[-1] == 8  # nerf_renderer.py:412
+        if not rays.is_cuda:
+            raise RuntimeError("diner_amd.NeRFRendererDGS runs on the GPU only (rays are on %s)" % rays.device)
+        return _f32c(rays)
+
+    def _next_seed(self) -> int:
+        self._calls += 1
+        return (int(self.seed) * 0x9E3779B97F4A7C15 + self._calls) & 0xFFFFFFFFFFFFFFFF
+
+    def _cfg(self, n_samples, n_candidates, n_gaussian, depth_diff_max=0.05) -> DinerSamplerCfg:
+        assert n_samples >= n_gaussian  # nerf_renderer.py:89
+        cfg = DinerSamplerCfg()
+        cfg.n_candidates, cfg.n_samples, cfg.n_gaussian = int(n_candidates), int(n_samples), int(n_gaussian)
+        cfg.depth_diff_max = float(depth_diff_max)
+        return cfg
+
+    # ------------------------------------------------------------------------------------------
+    # stages (reference signatures; keyword-only extras are build-only)
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def sample_coarse(self, rays, n_coarse=None, *, u_coarse=None):
+        """Stratified candidates (reference nerf_renderer.py:39-63): rays [SB,B,8] -> [SB,B,Kc]."""
+        n_coarse = n_coarse if n_coarse else self.n_coarse
+        r = self._check_rays(rays.reshape(1, -1, 8))
+        N = r.shape[1]
+        z = torch.empty((N, n_coarse), dtype=torch.float32, device=r.device)
+        u = None if u_coarse is None else _f32c(u_coarse).reshape(N, n_coarse)
+        check(_lib.lib().diner_sample_coarse(_ptr(r), N, n_coarse, _ptr(u), self._next_seed(), _ptr(z), _stream(r.device)),
+              "diner_sample_coarse")
+        return z.view(*rays.shape[:-1], n_coarse)
+
+    @torch.no_grad()
+    def sample_depthguided(self, rays, model, n_samples, n_candidates, depth_diff_max=0.05, n_gaussian=None, *,
+                           noise: Optional[Sequence[Optional[torch.Tensor]]] = None, z_cand=None,
+                           return_internals=False):
+        """Depth-guided short-list + gaussian samples (reference nerf_renderer.py:65-284).
+        Returns z [SB,NR,n_samples] *before* fill-up (0 = empty slot), like the reference.
+        ``noise=(u_coarse, n_gauss, u_fill)`` dense tensors for parity runs."""
+        n_gaussian = n_gaussian if n_gaussian is not None else self.n_gaussian
+        out = self._sample(rays, model, n_samples, n_candidates, n_gaussian, depth_diff_max, noise, z_cand,
+                           want_dg=True, want_lik=return_internals)
+        return (out["z_dg"], out) if return_internals else out["z_dg"]
+
+    def _sample(self, rays, model, K, NC, G, depth_diff_max, noise, z_cand, want_dg=False, want_lik=False):
+        r = self._check_rays(rays)
+        SB, NR, _ = r.shape
+        sc, _keep = self._scene(model, need_latent=False)
+        assert SB == sc.SB
+        cfg = self._cfg(K, NC, G, depth_diff_max)
+        dev = r.device
+        u_c = n_g = u_f = None
+        if noise is not None:
+            u_c, n_g, u_f = [None if t is None else _f32c(t).to(dev) for t in noise]
+            if u_c is not None: assert u_c.numel() == SB * NR * NC
+            if n_g is not None: assert n_g.numel() == SB * NR * G
+            if u_f is not None: assert u_f.numel() == SB * NR * K
+        zc = None if z_cand is None else _f32c(z_cand).to(dev)
+        z = torch.empty((SB, NR, K), dtype=torch.float32, device=dev)
+        z_dg = torch.empty_like(z) if want_dg else None
+        lik = torch.empty((SB, NR, NC), dtype=torch.float32, device=dev) if want_lik else None
+        check(_lib.lib().diner_sample_depthguided(C.byref(sc), _ptr(r), NR, C.byref(cfg), _ptr(u_c), _ptr(n_g), _ptr(u_f),
+                                                  _ptr(zc), self._next_seed(), _ptr(z), _ptr(z_dg), _ptr(lik),
+                                                  _stream(dev)), "diner_sample_depthguided")
+        return dict(z=z, z_dg=z_dg, likelihood=lik)
+
+    @torch.no_grad()
+    def fill_up_uniform_samples(self, z_samples, rays, *, u_fill=None):
+        """Uniform fill-up of the empty slots + sort (reference nerf_renderer.py:367-397)."""
+        r = self._check_rays(rays)
+        z = _f32c(z_samples)
+        K = z.shape[-1]
+        N = r.shape[0] * r.shape[1]
+        out = torch.empty_like(z)
+        u = None if u_fill is None else _f32c(u_fill).to(r.device)
+        check(_lib.lib().diner_fill_up_uniform_samples(_ptr(r), _ptr(z), N, K, _ptr(u), self._next_seed(), _ptr(out),
+                                                       _stream(r.device)), "diner_fill_up_uniform_samples")
+        return out
+
+    def render_points(self, model, rays, z_samp):
+        """rgb-sigma of the sample points (the ``model(points, viewdirs)`` calls of composite(),
+        reference nerf_renderer.py:304-339 + pixelnerf.py:55-145): -> [SB,B,K,4]."""
+        self._require_no_grad(model)
+        r = self._check_rays(rays)
+        z = _f32c(z_samp)
+        SB, NR, K = z.shape
+        sc, _keep = self._scene(model, need_latent=True)
+        assert SB == sc.SB  # pixelnerf.py:68
+        packed = self._mlp(model)
+        out = torch.empty((SB, NR, K, 4), dtype=torch.float32, device=r.device)
+        check(_lib.lib().diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, _ptr(out), _stream(r.device)),
+              "diner_render_points")
+        return out
+
+    def composite(self, model, rays, z_samp, *, rgbsigma=None):
+        """Alpha compositing (reference nerf_renderer.py:286-365) -> (weights, rgb, depth)."""
+        r = self._check_rays(rays)
+        z = _f32c(z_samp)
+        SB, NR, K = z.shape
+        if rgbsigma is None:
+            rgbsigma = self.render_points(model, rays, z)
+        c = _f32c(rgbsigma)
+        dev = r.device
+        weights = torch.empty((SB, NR, K), dtype=torch.float32, device=dev)
+        rgb = torch.empty((SB, NR, 3), dtype=torch.float32, device=dev)
+        depth = torch.empty((SB, NR), dtype=torch.float32, device=dev)
+        check(_lib.lib().diner_composite(_ptr(r), _ptr(z), _ptr(c), SB * NR, K, int(bool(self.white_bkgd)), _ptr(rgb),
+                                         _ptr(depth), _ptr(weights), _stream(dev)), "diner_composite")
+        return weights, rgb, depth
+
+    @staticmethod
+    def _require_no_grad(model):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in model.mlp_fine.parameters()):
+            raise RuntimeError(
+                "diner_amd.NeRFRendererDGS is forward-only (the backward of composite/PixelNeRF.forward is the "
+                "next scope row, SURVEY.md §8(f)-1): call it under torch.no_grad() for evaluation.")
+
+    # ------------------------------------------------------------------------------------------
+    def forward(self, model, rays, want_weights=False, *, noise=None, z_samples=None):
+        """Reference nerf_renderer.py:399-424.
+        :param model: ``PixelNeRF`` (encode() already called)
+        :param rays: [SB,B,8] = origin, direction, near, far
+        :param want_weights: also return the compositing weights [SB,B,K]
+        :param noise: (build-only) dense ``(u_coarse, n_gauss, u_fill)`` replacing the in-kernel RNG
+        :param z_samples: (build-only) inject sorted samples [SB,B,K] and skip the sampler
+        :return: ``out.fine.rgb`` [SB,B,3], ``out.fine.depth`` [SB,B], ``out.fine.weights`` iff requested
+        """
+        assert len(rays.shape) == 3
+        self._validate_model(model)
+        self._require_no_grad(model)
+        with torch.no_grad():
+            r = self._check_rays(rays)
+            SB, NR, _ = r.shape
+            K = int(self.n_samples)
+            dev = r.device
+            rgb = torch.empty((SB, NR, 3), dtype=torch.float32, device=dev)
+            depth = torch.empty((SB, NR), dtype=torch.float32, device=dev)
+            weights = torch.empty((SB, NR, K), dtype=torch.float32, device=dev) if want_weights else None
+            if z_samples is not None:
+                w_, rgb, depth = self.composite(model, r, z_samples)
+                weights = w_ if want_weights else None
+            else:
+                sc, _keep = self._scene(model, need_latent=True)
+                assert SB == sc.SB
+                packed = self._mlp(model)
+                cfg = self._cfg(K, self.n_depth_candidates, self.n_gaussian)
+                u_c = n_g = u_f = None
+                if noise is not None:
+                    u_c, n_g, u_f = [None if t is None else _f32c(t).to(dev) for t in noise]
+                ws = torch.empty(int(_lib.lib().diner_render_workspace_floats(SB, NR, K)), dtype=torch.float32, device=dev)
+                check(_lib.lib().diner_render(C.byref(sc), _ptr(packed), _ptr(r), NR, C.byref(cfg),
+                                              int(bool(self.white_bkgd)), _ptr(u_c), _ptr(n_g), _ptr(u_f),
+                                              self._next_seed(), _ptr(ws), _ptr(rgb), _ptr(depth), _ptr(weights),
+                                              _stream(dev)), "diner_render")
+        return RenderOutput(fine=self._format_outputs(weights, rgb, depth, want_weights=want_weights))
+
+    # alias asked for by the north_star text; the reference itself has no render_rays
+    render_rays = forward
+
+    def _format_outputs(self, weights, rgb, depth, want_weights):
+        out = RenderOutput(rgb=rgb, depth=depth)
+        if want_weights:
+            out.weights = weights
+        return out

@@ -1,0 +1,146 @@
+/*
+ * diner_hip.h -- C ABI of the MI355X-native DINER render path (libdiner_hip.so).
+ *
+ * The reference (tancredeguillou/diner) implements this path in pure Python/PyTorch and has no
+ * FFI; each entry point below therefore names the reference *Python* function it replaces
+ * (paths relative to the reference root).  The Python plug-in class
+ * diner_amd.NeRFRendererDGS (drop-in for src/models/nerf_renderer.py:12 NeRFRendererDGS, selected
+ * by the YAML key renderer.module, src/models/diner.py:48) binds these with ctypes; the binding a
+ * reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 unless stated otherwise; plain pointers and sizes
+ *    only, no torch types;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); nothing synchronises;
+ *  - every function returns 0 on success, <0 on error (DINER_E_*), never aborts the process;
+ *    diner_last_error() returns a thread-local message for the last failure;
+ *  - tensors use the reference's own shapes: SB scenes, NV source views, NR rays per scene,
+ *    NC candidates, K samples, G gaussian samples; rays [SB,NR,8] = origin(3) dir(3) near far.
+ */
+#ifndef DINER_HIP_H
+#define DINER_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DINER_OK 0
+#define DINER_E_INVALID (-1)  /* bad argument (NULL pointer, unsupported size) */
+#define DINER_E_LAUNCH (-2)   /* HIP launch / runtime failure */
+#define DINER_E_UNSUPPORTED (-3)
+
+#define DINER_D_LATENT 512 /* SpatialEncoder.latent_size, num_layers=4 (src/models/image_encoder.py:56) */
+#define DINER_D_HIDDEN 512 /* configs/train_diner_facescape.yaml:57 */
+#define DINER_D_IN 55      /* PE3 39 + viewdir 3 + PE1 13 (src/models/pixelnerf.py:18) */
+#define DINER_N_BLOCKS 5
+#define DINER_COMBINE_LAYER 3
+#define DINER_MAP_TEXEL 8  /* floats per packed map texel: nx ny nz depth sigma 0 0 0 */
+
+/* Per-scene state the renderer reads from the model:
+ * PixelNeRF buffers (src/models/pixelnerf.py:27-30,47-51) and SpatialEncoder state
+ * (src/models/image_encoder.py:92-95,214-218,271-272), with the maps re-packed once per
+ * encode() by diner_pack_maps / diner_pack_latent. */
+typedef struct DinerScene {
+    int32_t SB, NV;          /* scenes in the batch, source views */
+    int32_t H, W;            /* size of the depth / sigma / normal maps */
+    int32_t h, w, C;         /* latent map size and channels (C must be DINER_D_LATENT) */
+    int32_t num_freqs;       /* positional-encoding octaves (6) */
+    float image_w, image_h;  /* model.image_shape = (W, H) */
+    float feature_padding;   /* encoder.feature_padding in latent texels (32) */
+    float freq_factor;       /* 6.28 (configs/train_diner_facescape.yaml:51) */
+    const float *poses;      /* [SB,NV,4,4] world->camera */
+    const float *focal;      /* [SB,NV,2] */
+    const float *c;          /* [SB,NV,2] */
+    const float *maps;       /* [SB,NV,H,W,8] packed by diner_pack_maps */
+    const float *latent;     /* [SB,NV,h,w,C] packed by diner_pack_latent (may be NULL for the sampler) */
+} DinerScene;
+
+/* ResnetFC parameters in the reference's nn.Linear layout, weight [out,in]
+ * (src/models/resnetfc.py:72-127); input of diner_pack_mlp. */
+typedef struct DinerMlpRaw {
+    const float *lin_in_w, *lin_in_b;                  /* [512,55], [512] */
+    const float *lin_z_w[DINER_COMBINE_LAYER], *lin_z_b[DINER_COMBINE_LAYER]; /* [512,512] */
+    const float *fc0_w[DINER_N_BLOCKS], *fc0_b[DINER_N_BLOCKS];
+    const float *fc1_w[DINER_N_BLOCKS], *fc1_b[DINER_N_BLOCKS];
+    const float *lin_out_w, *lin_out_b;                /* [4,512], [4] */
+} DinerMlpRaw;
+
+typedef struct DinerSamplerCfg {
+    int32_t n_candidates;    /* NC  (n_depth_candidates, 1000) */
+    int32_t n_samples;       /* K   (n_samples, 40) */
+    int32_t n_gaussian;      /* G   (n_gaussian, 15), 0 <= G <= K */
+    float depth_diff_max;    /* 0.05 (src/models/nerf_renderer.py:67) */
+} DinerSamplerCfg;
+
+const char *diner_last_error(void);
+int diner_version(void);
+
+/* ---- once per encode(): re-pack the model's maps for the kernels ----------------------- */
+/* depths, depths_std [N,1,H,W], normals [N,3,H,W] (N = SB*NV) -> maps [N,H,W,8] */
+int diner_pack_maps(const float *depths, const float *depths_std, const float *normals,
+                    int64_t N, int32_t H, int32_t W, float *maps_out, void *stream);
+/* latent [N,C,h,w] (NCHW, src/models/image_encoder.py:271) -> [N,h,w,C] with the channel order
+ * the MLP kernel stages into LDS (C = 512) */
+int diner_pack_latent(const float *latent_nchw, int64_t N, int32_t C, int32_t h, int32_t w,
+                      float *latent_out, void *stream);
+/* ---- once per weight version: MFMA-fragment-ordered copy of the fusion MLP ------------- */
+int64_t diner_mlp_packed_floats(void);
+int diner_pack_mlp(const DinerMlpRaw *raw, float *packed_out, void *stream);
+
+/* ---- the hot path ---------------------------------------------------------------------- */
+/* Stage entry points with the reference's stage boundaries (for stage-level parity tests and for
+ * callers that use the stages on their own): */
+/* NeRFRendererDGS.sample_coarse (src/models/nerf_renderer.py:39-63): rays [N,8] -> z [N,NC];
+ * u_coarse [N,NC] or NULL (Philox keyed on seed). */
+int diner_sample_coarse(const float *rays, int64_t N, int32_t NC, const float *u_coarse, uint64_t seed,
+                        float *z_out, void *stream);
+/* NeRFRendererDGS.fill_up_uniform_samples (src/models/nerf_renderer.py:367-397): z_in [N,K] with
+ * 0 = empty slot -> z_out [N,K] filled and sorted; u_fill [N,K] (column i feeds the i-th empty
+ * slot) or NULL. */
+int diner_fill_up_uniform_samples(const float *rays, const float *z_in, int64_t N, int32_t K,
+                                  const float *u_fill, uint64_t seed, float *z_out, void *stream);
+
+/* Replaces NeRFRendererDGS.sample_coarse + sample_depthguided + fill_up_uniform_samples
+ * (src/models/nerf_renderer.py:39-63, 65-284, 367-397).  One ray per wavefront.
+ *   noise (parity mode, any may be NULL -> in-kernel Philox keyed on `seed`):
+ *     u_coarse [SB,NR,NC] U[0,1);  n_gauss [SB,NR,G] N(0,1), row used iff the ray has a hit;
+ *     u_fill [SB,NR,K] U[0,1), column i feeds the i-th empty slot of the ray.
+ *   z_cand  [SB,NR,NC] optional: inject the candidates instead of computing them (tests).
+ *   z_out   [SB,NR,K] sorted samples (what composite() consumes).
+ *   z_dg_out [SB,NR,K] optional: samples BEFORE fill-up, kept candidates first (0 = empty),
+ *            gaussian draws in the last G slots (the return value of sample_depthguided).
+ *   lik_out [SB,NR,NC] optional: per-candidate likelihood max over views (:129). */
+int diner_sample_depthguided(const DinerScene *scene, const float *rays, int64_t NR,
+                             const DinerSamplerCfg *cfg, const float *u_coarse,
+                             const float *n_gauss, const float *u_fill, const float *z_cand,
+                             uint64_t seed, float *z_out, float *z_dg_out, float *lik_out,
+                             void *stream);
+
+/* Replaces the model evaluation inside composite(): points = o + z*d (:304-307) and
+ * PixelNeRF.forward (src/models/pixelnerf.py:55-145) incl. PositionalEncoding.forward,
+ * SpatialEncoder.index / index_depth and ResnetFC.forward.  z [SB,NR,K] -> rgbsigma [SB,NR,K,4].
+ * mlp_packed from diner_pack_mlp. */
+int diner_render_points(const DinerScene *scene, const float *mlp_packed, const float *rays,
+                        const float *z, int64_t NR, int32_t K, float *rgbsigma_out, void *stream);
+
+/* Replaces the alpha compositing of composite() (src/models/nerf_renderer.py:299-301,341-360).
+ * N rays (= SB*NR).  weights_out [N,K] optional. */
+int diner_composite(const float *rays, const float *z, const float *rgbsigma, int64_t N, int32_t K,
+                    int32_t white_bkgd, float *rgb_out, float *depth_out, float *weights_out,
+                    void *stream);
+
+/* Replaces NeRFRendererDGS.forward (src/models/nerf_renderer.py:399-424): the three stages
+ * back to back on `stream`.  workspace: device buffer of diner_render_workspace_floats(...)
+ * floats (holds z and rgbsigma). */
+int64_t diner_render_workspace_floats(int64_t SB, int64_t NR, int32_t K);
+int diner_render(const DinerScene *scene, const float *mlp_packed, const float *rays, int64_t NR,
+                 const DinerSamplerCfg *cfg, int32_t white_bkgd, const float *u_coarse,
+                 const float *n_gauss, const float *u_fill, uint64_t seed, float *workspace,
+                 float *rgb_out, float *depth_out, float *weights_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DINER_HIP_H */
