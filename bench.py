@@ -68,6 +68,7 @@ def main():
                     "4096 = the reference's ray_batch_size (src/models/diner.py:57)")
     ap.add_argument("--cpu-sample-rays", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32"], help="arithmetic of the fusion-MLP GEMMs")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -94,6 +95,7 @@ def main():
     weights = synth.make_mlp_weights(1, bias_scale=0.1)
     model = model_from_scene(scene, weights, device=dev, latent=latent)
     rend = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G, white_bkgd=scene.white_bkgd)
+    rend.precision = args.precision
     # each rank renders its own target pose of the scene (weak scaling)
     scene.target_extrinsics = synth.look_at_origin_w2c(0.1 + 0.07 * rank, scene.meta["cam_radius"])
     rays = torch.from_numpy(scene.target_rays()).to(dev)  # [1, H*W, 8]

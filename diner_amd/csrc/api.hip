@@ -37,6 +37,9 @@ int launch_sampler(const DinerScene &, const float *, int64_t, const DinerSample
 int launch_sample_coarse(const float *, int64_t, int, const float *, uint64_t, float *, hipStream_t);
 int launch_fill_up(const float *, const float *, int64_t, int, const float *, uint64_t, float *, hipStream_t);
 int launch_points_mlp(const DinerScene &, const float *, const float *, const float *, int64_t, int, float *, hipStream_t);
+int64_t mlp_f16_packed_floats();
+int launch_pack_mlp_f16(const DinerMlpRaw &, float *, hipStream_t);
+int launch_points_mlp_f16(const DinerScene &, const float *, const float *, const float *, int64_t, int, float *, hipStream_t);
 
 static int bad(const char *msg)
 {
@@ -91,7 +94,7 @@ int diner_pack_latent(const float *latent_nchw, int64_t N, int32_t C, int32_t h,
     return launch_pack_latent(latent_nchw, N, C, h, w, latent_out, (hipStream_t)stream);
 }
 
-int64_t diner_mlp_packed_floats(void) { return mlp_packed_floats(); }
+int64_t diner_mlp_packed_floats(void) { return mlp_packed_floats() + mlp_f16_packed_floats(); }
 
 int diner_pack_mlp(const DinerMlpRaw *raw, float *packed_out, void *stream)
 {
@@ -99,7 +102,9 @@ int diner_pack_mlp(const DinerMlpRaw *raw, float *packed_out, void *stream)
     const float *const *p = (const float *const *)raw;
     for (size_t i = 0; i < sizeof(DinerMlpRaw) / sizeof(float *); ++i)
         if (!p[i]) return bad("pack_mlp: NULL weight pointer");
-    return launch_pack_mlp(*raw, packed_out, (hipStream_t)stream);
+    const int rc = launch_pack_mlp(*raw, packed_out, (hipStream_t)stream);
+    if (rc) return rc;
+    return launch_pack_mlp_f16(*raw, packed_out + mlp_packed_floats(), (hipStream_t)stream);
 }
 
 int diner_sample_coarse(const float *rays, int64_t N, int32_t NC, const float *u_coarse, uint64_t seed, float *z_out,
@@ -131,14 +136,17 @@ int diner_sample_depthguided(const DinerScene *scene, const float *rays, int64_t
 }
 
 int diner_render_points(const DinerScene *scene, const float *mlp_packed, const float *rays, const float *z,
-                        int64_t NR, int32_t K, float *rgbsigma_out, void *stream)
+                        int64_t NR, int32_t K, int32_t precision, float *rgbsigma_out, void *stream)
 {
     int rc;
     if ((rc = check_scene(scene, true))) return rc;
     if (NR < 0 || K < 1) return bad("render_points: bad NR / K");
     if (!mlp_packed) return bad("render_points: mlp_packed is NULL");
     if (NR > 0 && scene->SB > 0 && (!rays || !z || !rgbsigma_out)) return bad("render_points: NULL rays / z / out");
-    return launch_points_mlp(*scene, mlp_packed, rays, z, NR, K, rgbsigma_out, (hipStream_t)stream);
+    if (precision == DINER_PRECISION_FP32) return launch_points_mlp(*scene, mlp_packed, rays, z, NR, K, rgbsigma_out, (hipStream_t)stream);
+    if (precision == DINER_PRECISION_F16X3)
+        return launch_points_mlp_f16(*scene, mlp_packed + mlp_packed_floats(), rays, z, NR, K, rgbsigma_out, (hipStream_t)stream);
+    return bad("render_points: unknown precision");
 }
 
 int diner_composite(const float *rays, const float *z, const float *rgbsigma, int64_t N, int32_t K,
@@ -152,7 +160,7 @@ int diner_composite(const float *rays, const float *z, const float *rgbsigma, in
 int64_t diner_render_workspace_floats(int64_t SB, int64_t NR, int32_t K) { return SB * NR * (int64_t)K * 5; }
 
 int diner_render(const DinerScene *scene, const float *mlp_packed, const float *rays, int64_t NR,
-                 const DinerSamplerCfg *cfg, int32_t white_bkgd, const float *u_coarse, const float *n_gauss,
+                 const DinerSamplerCfg *cfg, int32_t white_bkgd, int32_t precision, const float *u_coarse, const float *n_gauss,
                  const float *u_fill, uint64_t seed, float *workspace, float *rgb_out, float *depth_out,
                  float *weights_out, void *stream)
 {
@@ -166,7 +174,7 @@ int diner_render(const DinerScene *scene, const float *mlp_packed, const float *
     if ((rc = diner_sample_depthguided(scene, rays, NR, cfg, u_coarse, n_gauss, u_fill, nullptr, seed, z, nullptr,
                                        nullptr, stream)))
         return rc;
-    if ((rc = diner_render_points(scene, mlp_packed, rays, z, NR, cfg->n_samples, rgbsigma, stream))) return rc;
+    if ((rc = diner_render_points(scene, mlp_packed, rays, z, NR, cfg->n_samples, precision, rgbsigma, stream))) return rc;
     return diner_composite(rays, z, rgbsigma, N, cfg->n_samples, white_bkgd, rgb_out, depth_out, weights_out, stream);
 }
 

@@ -19,12 +19,7 @@ __global__ void pack_maps_kernel(const float *__restrict__ d, const float *__res
     out[i * 2 + 1] = make_float4(s[i], 0.f, 0.f, 0.f);
 }
 
-// Position of channel k inside a packed latent texel: the order in which the fused MLP kernel lays
-// a row of its LDS A-operand image ([k/8][k%2][row][(k/2)%4], see points_mlp.hip), so that one
-// 16-byte load of a texel is one 16-byte LDS store.
-__host__ __device__ inline int latent_chan_pos(int k) { return (((k >> 3) * 2 + (k & 1)) << 2) + ((k >> 1) & 3); }
-
-// latent [N,C,h,w] -> [N,h,w,C'] (C' = permuted channels).  Tile: 32 pixels x C channels via LDS.
+// latent [N,C,h,w] -> [N,h,w,C] (a texel = 2 KB contiguous).  Tile: 32 pixels x C channels via LDS.
 template <int C>
 __global__ __launch_bounds__(256) void pack_latent_kernel(const float *__restrict__ in, int64_t hw,
                                                           float *__restrict__ out)
@@ -39,7 +34,7 @@ __global__ __launch_bounds__(256) void pack_latent_kernel(const float *__restric
     float *dst = out + (img * hw + p0) * C;
     for (int i = threadIdx.x; i < 32 * C; i += 256) {
         const int p = i / C, k = i - p * C;
-        if (p0 + p < hw) dst[(int64_t)p * C + latent_chan_pos(k)] = tile[p][k];
+        if (p0 + p < hw) dst[(int64_t)p * C + k] = tile[p][k];
     }
 }
 

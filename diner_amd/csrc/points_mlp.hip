@@ -267,13 +267,12 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_kernel(DinerScene s, c
                 const Tap t = taps[r];
 #pragma unroll
                 for (int half = 0; half < 2; ++half) {
-                    const int q = lane + 64 * half;  // float4 index inside the packed texel == A image block
+                    const int q = lane + 64 * half;  // float4 index inside the texel: channels 4q..4q+3
                     const f32x4 a = lat[t.o00 + q], bb = lat[t.o01 + q], c = lat[t.o10 + q], d = lat[t.o11 + q];
-                    f32x4 o;
 #pragma unroll
                     for (int i = 0; i < 4; ++i)  // ATen's accumulation order nw,ne,sw,se with contracted FMAs
-                        o[i] = __builtin_fmaf(d[i], t.se, __builtin_fmaf(c[i], t.sw, __builtin_fmaf(bb[i], t.ne, a[i] * t.nw)));
-                    A4[q * TILE_P + r] = o;
+                        A[a_off(r, 4 * q + i)] =
+                            __builtin_fmaf(d[i], t.se, __builtin_fmaf(c[i], t.sw, __builtin_fmaf(bb[i], t.ne, a[i] * t.nw)));
                 }
             }
             __syncthreads();

@@ -74,6 +74,9 @@ class NeRFRendererDGS(torch.nn.Module):
         self.eval_batch_size = eval_batch_size
         self.white_bkgd = white_bkgd
         self.seed = 0            # base seed of the in-kernel Philox generator (perf mode)
+        # arithmetic of the fusion-MLP GEMMs (build-only extra): "f16x3" = fp32 operands split into fp16
+        # hi+lo, 3 fp16 MFMAs per product, fp32 accumulate (fp32-grade, ~3x faster); "fp32" = fp32 MFMA
+        self.precision = "f16x3"
         # profiling hook (bench.py): when a list, forward() launches the three stage kernels through
         # their own C-ABI entry points (exactly what diner_render does internally) and appends
         # (ev0, ev1, ev2, ev3) torch.cuda.Events bracketing sampler | points+MLP | compositing
@@ -266,7 +269,8 @@ class NeRFRendererDGS(torch.nn.Module):
         assert SB == sc.SB  # pixelnerf.py:68
         packed = self._mlp(model)
         out = torch.empty((SB, NR, K, 4), dtype=torch.float32, device=r.device)
-        check(_lib.lib().diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, _ptr(out), _stream(r.device)),
+        check(_lib.lib().diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, _lib.PRECISIONS[self.precision],
+                                             _ptr(out), _stream(r.device)),
               "diner_render_points")
         return out
 
@@ -329,7 +333,7 @@ class NeRFRendererDGS(torch.nn.Module):
                 L, st, seed = _lib.lib(), _stream(dev), self._next_seed()
                 if self.stage_events is None:
                     check(L.diner_render(C.byref(sc), _ptr(packed), _ptr(r), NR, C.byref(cfg), int(bool(self.white_bkgd)),
-                                         _ptr(u_c), _ptr(n_g), _ptr(u_f), seed, _ptr(ws), _ptr(rgb), _ptr(depth),
+                                         _lib.PRECISIONS[self.precision], _ptr(u_c), _ptr(n_g), _ptr(u_f), seed, _ptr(ws), _ptr(rgb), _ptr(depth),
                                          _ptr(weights), st), "diner_render")
                 else:
                     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -338,7 +342,8 @@ class NeRFRendererDGS(torch.nn.Module):
                     check(L.diner_sample_depthguided(C.byref(sc), _ptr(r), NR, C.byref(cfg), _ptr(u_c), _ptr(n_g), _ptr(u_f),
                                                      None, seed, _ptr(z), None, None, st), "diner_sample_depthguided")
                     ev[1].record()
-                    check(L.diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, _ptr(c), st),
+                    check(L.diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, _lib.PRECISIONS[self.precision],
+                                                _ptr(c), st),
                           "diner_render_points")
                     ev[2].record()
                     check(L.diner_composite(_ptr(r), _ptr(z), _ptr(c), SB * NR, K, int(bool(self.white_bkgd)), _ptr(rgb),

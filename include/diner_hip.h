@@ -38,6 +38,13 @@ extern "C" {
 #define DINER_COMBINE_LAYER 3
 #define DINER_MAP_TEXEL 8  /* floats per packed map texel: nx ny nz depth sigma 0 0 0 */
 
+/* Arithmetic of the fusion-MLP GEMMs (everything else is fp32 in both modes):
+ *  FP32  : v_mfma_f32_32x32x2_f32, bit-identical to a k-ordered fmaf chain;
+ *  F16X3 : every fp32 operand split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate
+ *          (fp32-grade: operand error <= 2^-23 relative, dropped lo*lo term <= 2^-22). */
+#define DINER_PRECISION_FP32 0
+#define DINER_PRECISION_F16X3 1
+
 /* Per-scene state the renderer reads from the model:
  * PixelNeRF buffers (src/models/pixelnerf.py:27-30,47-51) and SpatialEncoder state
  * (src/models/image_encoder.py:92-95,214-218,271-272), with the maps re-packed once per
@@ -85,7 +92,8 @@ int diner_pack_maps(const float *depths, const float *depths_std, const float *n
  * the MLP kernel stages into LDS (C = 512) */
 int diner_pack_latent(const float *latent_nchw, int64_t N, int32_t C, int32_t h, int32_t w,
                       float *latent_out, void *stream);
-/* ---- once per weight version: MFMA-fragment-ordered copy of the fusion MLP ------------- */
+/* ---- once per weight version: MFMA-fragment-ordered copies of the fusion MLP (one image per
+ * precision mode, both in the same buffer) ------------------------------------------------ */
 int64_t diner_mlp_packed_floats(void);
 int diner_pack_mlp(const DinerMlpRaw *raw, float *packed_out, void *stream);
 
@@ -123,7 +131,8 @@ int diner_sample_depthguided(const DinerScene *scene, const float *rays, int64_t
  * SpatialEncoder.index / index_depth and ResnetFC.forward.  z [SB,NR,K] -> rgbsigma [SB,NR,K,4].
  * mlp_packed from diner_pack_mlp. */
 int diner_render_points(const DinerScene *scene, const float *mlp_packed, const float *rays,
-                        const float *z, int64_t NR, int32_t K, float *rgbsigma_out, void *stream);
+                        const float *z, int64_t NR, int32_t K, int32_t precision, float *rgbsigma_out,
+                        void *stream);
 
 /* Replaces the alpha compositing of composite() (src/models/nerf_renderer.py:299-301,341-360).
  * N rays (= SB*NR).  weights_out [N,K] optional. */
@@ -136,7 +145,7 @@ int diner_composite(const float *rays, const float *z, const float *rgbsigma, in
  * floats (holds z and rgbsigma). */
 int64_t diner_render_workspace_floats(int64_t SB, int64_t NR, int32_t K);
 int diner_render(const DinerScene *scene, const float *mlp_packed, const float *rays, int64_t NR,
-                 const DinerSamplerCfg *cfg, int32_t white_bkgd, const float *u_coarse,
+                 const DinerSamplerCfg *cfg, int32_t white_bkgd, int32_t precision, const float *u_coarse,
                  const float *n_gauss, const float *u_fill, uint64_t seed, float *workspace,
                  float *rgb_out, float *depth_out, float *weights_out, void *stream);
 

@@ -32,9 +32,14 @@ def model_for(g, dev):
     return _models[g.name]
 
 
-def renderer_for(g):
+PRECISIONS = ["fp32", "f16x3"]
+
+
+def renderer_for(g, precision="f16x3"):
     from diner_amd import NeRFRendererDGS
-    return NeRFRendererDGS(n_samples=g.K, n_depth_candidates=g.NC, n_gaussian=g.G, white_bkgd=g.scene.white_bkgd)
+    r = NeRFRendererDGS(n_samples=g.K, n_depth_candidates=g.NC, n_gaussian=g.G, white_bkgd=g.scene.white_bkgd)
+    r.precision = precision
+    return r
 
 
 def T(a, dev):
@@ -79,17 +84,19 @@ def test_fill_up(golden, dev):
     np.testing.assert_array_equal(z.cpu().numpy()[0], golden["z_fill"])
 
 
-def test_points_rgbsigma_vs_reference(golden, dev):
-    r = renderer_for(golden)
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_points_rgbsigma_vs_reference(golden, dev, precision):
+    r = renderer_for(golden, precision)
     m = model_for(golden, dev)
     with torch.no_grad():
         out = r.render_points(m, T(golden.rays, dev), T(golden["z_fill"], dev)[None]).cpu().numpy()[0]
     _check_rgbsigma(out, golden["rgbsigma"])
 
 
-def test_points_rgbsigma_vs_oracle(golden, dev):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_points_rgbsigma_vs_oracle(golden, dev, precision):
     from oracle.oracle import Oracle
-    r = renderer_for(golden)
+    r = renderer_for(golden, precision)
     m = model_for(golden, dev)
     rays = golden.rays[0]
     z = golden["z_fill"]
@@ -98,9 +105,12 @@ def test_points_rgbsigma_vs_oracle(golden, dev):
     xyz = rays[:, None, :3] + z[..., None] * rays[:, None, 3:6]
     dirs = np.broadcast_to(rays[:, None, 3:6], xyz.shape)
     orc = Oracle(golden.scene, golden.weights).points_forward(xyz.reshape(-1, 3), dirs.reshape(-1, 3)).reshape(out.shape)
-    # same fp32 fma-chain order in both: expect agreement well below the 1e-4 bar
+    # fp32 mode: same fp32 fma-chain order in both; f16x3: fp32-grade split products.
+    # Either way expect agreement well below the 1e-4 bar.
     _check_rgbsigma(out, orc)
-    assert np.abs(out[..., :3] - orc[..., :3]).max() < 2e-5
+    d = np.abs(out - orc)
+    print(f"{golden.name} {precision}: max|drgb|={d[..., :3].max():.2e} max|dsigma|={d[..., 3].max():.2e} (sigma max {orc[..., 3].max():.1f})")
+    assert d[..., :3].max() < 3e-5
 
 
 def test_composite(golden, dev):
@@ -111,9 +121,10 @@ def test_composite(golden, dev):
     np.testing.assert_allclose(depth.cpu().numpy()[0], golden["depth"], rtol=0, atol=2e-6)
 
 
-def test_forward_with_injected_samples(golden, dev):
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_with_injected_samples(golden, dev, precision):
     """north_star parity clause: RGB within 1e-4 of the reference renderer for identical samples."""
-    r = renderer_for(golden)
+    r = renderer_for(golden, precision)
     m = model_for(golden, dev)
     with torch.no_grad():
         out = r(m, T(golden.rays, dev), want_weights=True, z_samples=T(golden["z_fill"], dev)[None])
@@ -122,8 +133,9 @@ def test_forward_with_injected_samples(golden, dev):
     np.testing.assert_allclose(out.fine.weights.cpu().numpy()[0], golden["weights"], rtol=0, atol=1e-4)
 
 
-def test_forward_end_to_end_replayed_noise(golden, dev):
-    r = renderer_for(golden)
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_forward_end_to_end_replayed_noise(golden, dev, precision):
+    r = renderer_for(golden, precision)
     m = model_for(golden, dev)
     noise = tuple(T(n, dev)[None] for n in golden.noise)
     with torch.no_grad():

@@ -26,7 +26,9 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/diner_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == names, "ctypes table and header drifted apart"
     assert lib.diner_version() == 1
-    assert lib.diner_mlp_packed_floats() == 16 * 7 * 256 + 13 * 16 * 64 * 256 + 64 * 256 + 14 * 512 + 32
+    fp32_img = 16 * 7 * 256 + 13 * 16 * 64 * 256 + 64 * 256 + 14 * 512 + 32
+    f16_img = (16 * 4 * 1024 + 13 * 16 * 32 * 1024 + 32 * 1024) // 2 + 14 * 512 + 32
+    assert lib.diner_mlp_packed_floats() == fp32_img + f16_img
 
 
 def test_argument_validation_returns_codes():
