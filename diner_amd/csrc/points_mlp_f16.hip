@@ -9,9 +9,9 @@
 //     a*w ~= a_hi*w_hi + a_hi*w_lo + a_lo*w_hi    (dropped a_lo*w_lo <= 2^-22 |a w|)
 //
 // v_mfma_f32_32x32x16_f16 keeps fp16 subnormal inputs (probed on gfx950: tools/mfma_probe.hip), so
-// the representation error of an operand is max(2^-23 |v|, 2^-25 * scale): fp32-grade.  Activations
-// are stored scaled by 2^-4 and weights by 2^+4 (exact), which moves the fp16 overflow point of an
-// activation to 1.0e6 and keeps typical weights' low halves normal; the products are unscaled.
+// the representation error of an operand is max(2^-23 |v|, 2^-25): fp32-grade.  The whole hidden
+// state is carried scaled by 2^-4 (inputs and biases are pre-scaled, the head multiplies by 16: all
+// exact), which moves the fp16 overflow point of an activation to 1.0e6 at no cost in the hot loops.
 // An activation beyond the fp16 range becomes inf and the outputs NaN -- loud, never silently wrong.
 // Parity with the reference stays inside the 1e-4 bar (tests/test_gpu_parity.py, both precisions).
 //
@@ -36,12 +36,11 @@ constexpr int HID = DINER_D_HIDDEN;
 constexpr int NKB_FULL = HID / 16;  // 32 k-blocks of 16
 constexpr int NKB_IN = 4;           // lin_in: 55 inputs padded to 64
 constexpr int UNITS = 64 * TILE_P;  // 16-byte units per A image (hi or lo): [k/8 (64)][row (64)], 64 KiB
-constexpr float ACT_SCALE = 0.0625f;   // activations stored * 2^-4
-constexpr float W_SCALE = 16.0f;       // weights stored * 2^+4
+constexpr float ACT_SCALE = 0.0625f;   // the hidden state, its inputs and the biases are carried * 2^-4
 
 // ---- packed weight image (halfs) --------------------------------------------------------------
 // layer block: [col_tile][kb][part hi=0/lo=1][lane][8]: lane = h*32+c holds
-//   W[n = 32*col_tile + c][k = 16*kb + 8*h + j] * 16, j = 0..7, split into hi / lo
+//   W[n = 32*col_tile + c][k = 16*kb + 8*h + j], j = 0..7, split into hi / lo
 constexpr int64_t W_FULL = 16LL * NKB_FULL * 2 * 64 * 8;  // halfs of one 512x512 layer (= 512*512*2)
 constexpr int64_t W_IN = 16LL * NKB_IN * 2 * 64 * 8;
 constexpr int64_t W_OUT = 1LL * NKB_FULL * 2 * 64 * 8;
@@ -58,11 +57,11 @@ __global__ void pack_kernel(DinerMlpRaw raw, _Float16 *__restrict__ outw, float 
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < BIAS_FLOATS) {
-        if (i >= 14 * 512) { const int c = (int)(i - 14 * 512); outb[i] = c < 4 ? raw.lin_out_b[c] : 0.0f; }
+        if (i >= 14 * 512) { const int c = (int)(i - 14 * 512); outb[i] = c < 4 ? raw.lin_out_b[c] * ACT_SCALE : 0.0f; }
         else {
             const int slot = (int)(i / 512), c = (int)(i % 512);
             const float *src = slot == 0 ? raw.lin_in_b : slot < 4 ? raw.lin_z_b[slot - 1] : slot < 9 ? raw.fc0_b[slot - 4] : raw.fc1_b[slot - 9];
-            outb[i] = src[c];
+            outb[i] = src[c] * ACT_SCALE;
         }
     }
     if (i >= W_HALFS) return;
@@ -78,7 +77,7 @@ __global__ void pack_kernel(DinerMlpRaw raw, _Float16 *__restrict__ outw, float 
     const int64_t blk = rel >> 10;
     const int kb = (int)(blk % nkb), tile = (int)(blk / nkb);
     const int n = tile * 32 + (lane & 31), k = kb * 16 + 8 * (lane >> 5) + j;
-    const float v = (n < out_dim && k < in_dim) ? w[(int64_t)n * in_dim + k] * W_SCALE : 0.0f;
+    const float v = (n < out_dim && k < in_dim) ? w[(int64_t)n * in_dim + k] : 0.0f;
     const _Float16 hi = (_Float16)v;
     outw[i] = part == 0 ? hi : (_Float16)(v - (float)hi);
 }
@@ -89,9 +88,8 @@ __global__ void pack_kernel(DinerMlpRaw raw, _Float16 *__restrict__ outw, float 
 // writes of the accumulator store all bank-conflict-free.
 __device__ __forceinline__ int unit(int u, int row) { return u * TILE_P + (row ^ (u & 63)); }
 
-__device__ __forceinline__ void split(float v, _Float16 &hi, _Float16 &lo)
+__device__ __forceinline__ void split(float s, _Float16 &hi, _Float16 &lo)
 {
-    const float s = v * ACT_SCALE;
     hi = (_Float16)s;
     lo = (_Float16)(s - (float)hi);
 }
@@ -152,10 +150,17 @@ __device__ __forceinline__ void acc_add_bias(f32x16 (&acc)[2][CT], const float *
 
 // relu(acc) -> split -> LDS A images: this wave's 64 columns become k = 64w .. 64w+63 of the next layer.
 // Lane c holds column k = base + c; neighbouring lanes hold neighbouring k, so an even/odd lane pair
-// exchanges one value per register pair and each lane writes one packed (k, k+1) dword.
+// swaps one value per register pair (DPP quad_perm, no LDS) and each lane writes one packed (k, k+1)
+// dword per image.
+__device__ __forceinline__ float swap_xor1(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
+}
 __device__ __forceinline__ void store_relu(const f32x16 (&acc)[2][CT], _Float16 *Ahi, _Float16 *Alo, int wave, int lane)
 {
-    const int c = lane & 31, h = lane >> 5, odd = lane & 1;
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    const int c = lane & 31, h = lane >> 5;
+    const bool odd = lane & 1;
 #pragma unroll
     for (int tn = 0; tn < CT; ++tn) {
         const int k = wave * (32 * CT) + tn * 32 + c, u = k >> 3, j0 = (k & 7) & ~1;
@@ -164,16 +169,18 @@ __device__ __forceinline__ void store_relu(const f32x16 (&acc)[2][CT], _Float16 
 #pragma unroll
             for (int i = 0; i < 16; i += 2) {
                 // even lane writes (k, k+1) of register i's row; odd lane writes (k-1, k) of register i+1's row
-                const float mine_keep = odd ? acc[tm][tn][i + 1] : acc[tm][tn][i];
-                const float mine_give = odd ? acc[tm][tn][i] : acc[tm][tn][i + 1];
-                const float got = __shfl_xor(mine_give, 1, 64);
-                const float v0 = odd ? got : mine_keep, v1 = odd ? mine_keep : got;  // values at k even, k odd
-                const int row = tm * 32 + 8 * (i >> 2) + 4 * h + (i & 3) + odd;     // C/D layout of the 32x32 MFMA
+                float a0 = acc[tm][tn][i], a1 = acc[tm][tn][i + 1];
+                asm volatile("" : "+v"(a0), "+v"(a1));  // keep the two extracts static (no dynamic vector index)
+                a0 = a0 > 0.0f ? a0 : 0.0f;
+                a1 = a1 > 0.0f ? a1 : 0.0f;
+                const float keep = odd ? a1 : a0, give = odd ? a0 : a1;
+                const float got = swap_xor1(give);
+                const float v0 = odd ? got : keep, v1 = odd ? keep : got;           // values at k even, k odd
+                const int row = tm * 32 + 8 * (i >> 2) + 4 * h + (i & 3) + (odd ? 1 : 0);  // C/D layout of the 32x32 MFMA
                 _Float16 h0, l0, h1, l1;
-                split(v0 > 0.0f ? v0 : 0.0f, h0, l0);
-                split(v1 > 0.0f ? v1 : 0.0f, h1, l1);
+                split(v0, h0, l0);
+                split(v1, h1, l1);
                 const int o = unit(u, row) * 8 + j0;
-                typedef _Float16 h2 __attribute__((ext_vector_type(2)));
                 *(h2 *)(Ahi + o) = h2{h0, h1};
                 *(h2 *)(Alo + o) = h2{l0, l1};
             }
@@ -250,7 +257,7 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
                     val = sinf(__builtin_fmaf(delta, s.freq_factor * (float)(1 << (j >> 1)), (j & 1) ? half_pi : 0.0f)); }
                 else val = 0.0f;
                 _Float16 hi, lo;
-                split(val, hi, lo);
+                split(val * ACT_SCALE, hi, lo);
                 const int o = unit(e >> 3, row) * 8 + (e & 7);
                 Ahi[o] = hi;
                 Alo[o] = lo;
@@ -294,7 +301,7 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
                     for (int i = 0; i < 4; ++i) {  // ATen's accumulation order nw,ne,sw,se with contracted FMAs
                         const float o = __builtin_fmaf(d[i], t.se, __builtin_fmaf(c[i], t.sw, __builtin_fmaf(bb[i], t.ne, a[i] * t.nw)));
                         _Float16 hi, lo;
-                        split(o, hi, lo);
+                        split(o * ACT_SCALE, hi, lo);
                         vh[half * 4 + i] = hi;
                         vl[half * 4 + i] = lo;
                     }
@@ -368,7 +375,7 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
                 const int rr = wave * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
                 const int64_t pp = tile * TILE_P + rr;
                 if (pp < P) {
-                    const float val = o[i];                                            // pixelnerf.py:139-143
+                    const float val = o[i] * (1.0f / ACT_SCALE);                       // pixelnerf.py:139-143
                     rgbsigma[((int64_t)sb * P + pp) * 4 + c] = c < 3 ? 1.0f / (1.0f + expf(-val)) : (val > 0.0f ? val : 0.0f);
                 }
             }
