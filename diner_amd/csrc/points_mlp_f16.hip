@@ -19,6 +19,22 @@
 // instruction, so three of them are ~5x faster per product.  What then bounds the kernel is the
 // weight stream (1 MiB per layer per 64-point tile from L2) and the activation re-staging between
 // layers, see DESIGN.md §4.
+//
+// Differences from the fp32 kernel, all driven by that:
+//   * the GEMMs are evaluated TRANSPOSED (C^T[feature][point] = W * act^T: the weight fragment is the
+//     MFMA A operand, the activation fragment the B operand).  A lane of the 32x32 accumulator then
+//     holds 4 consecutive features of one point in 4 consecutive registers -- exactly 4 consecutive k
+//     of the next layer -- so re-staging an activation tile is convert + one 8-byte LDS store per
+//     image per 4 values, with no cross-lane traffic;
+//   * weights stream through a 2-deep register ring written with inline-asm loads and counted waits
+//     (hipcc sinks ordinary prefetch loads to their first use); measured with in-kernel stamps the GEMM
+//     phases already run at the chip's sustained fp16-MFMA rate on random data (~1.5 PFLOP/s, clock-
+//     limited), so a deeper ring buys nothing and the registers go to the view-sum instead;
+//   * persistent workgroups (one per CU): all biases are staged in LDS once, and in each round the
+//     workgroups of one XCD take a contiguous run of tiles, so neighbouring texels share one L2.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include "common.hpp"
 
 namespace diner {
@@ -50,7 +66,7 @@ constexpr int64_t OFF_FC0 = OFF_LIN_Z + 3 * W_FULL;
 constexpr int64_t OFF_FC1 = OFF_FC0 + 5 * W_FULL;
 constexpr int64_t OFF_LIN_OUT = OFF_FC1 + 5 * W_FULL;
 constexpr int64_t W_HALFS = OFF_LIN_OUT + W_OUT;
-constexpr int64_t BIAS_FLOATS = 14 * 512 + 32;   // fp32 biases appended after the halfs
+constexpr int BIAS_FLOATS = 14 * 512 + 32;       // fp32 biases appended after the halfs
 constexpr int64_t PACKED_FLOATS = W_HALFS / 2 + BIAS_FLOATS;
 
 __global__ void pack_kernel(DinerMlpRaw raw, _Float16 *__restrict__ outw, float *__restrict__ outb)
@@ -94,97 +110,122 @@ __device__ __forceinline__ void split(float s, _Float16 &hi, _Float16 &lo)
     lo = (_Float16)(s - (float)hi);
 }
 
-// acc[tm][tn] += A[64 x 16*NKB] * W^T for this wave's CT column tiles, three fp16 MFMAs per product.
+// ---- weight stream: inline-asm loads + counted waits ------------------------------------------------
+// hipcc sinks ordinary prefetch loads down to their first use (and then waits vmcnt(0) every k-block),
+// so the register ring is written with asm loads and asm waits.  All VMEM traffic inside the GEMM loop
+// is these loads, so the counts below are exact; any compiler-issued load around the loop can only make
+// a wait stricter, never too weak (vmcnt retires in issue order).
+// The address is a per-lane VGPR pair on purpose: with an SGPR base the compiler may reload a spilled
+// SGPR (v_readlane = VALU write) right in front of the asm, and the 5 wait states gfx9 requires between
+// a VALU-written SGPR and a VMEM instruction reading it are not inserted for inline asm (seen as a
+// memory fault on the box).  A VGPR address has no such software-managed hazard.
+template <int OFF>
+__device__ __forceinline__ void wload(h8 &dst, const char *ptr)
+{
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=&v"(dst) : "v"(ptr), "n"(OFF) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wwait(h8 (&w)[CT][2])
+{
+    static_assert(CT == 2, "operand list");
+    asm volatile("s_waitcnt vmcnt(%4)" : "+v"(w[0][0]), "+v"(w[0][1]), "+v"(w[1][0]), "+v"(w[1][1]) : "n"(N));
+}
+
+// acc[tn][tp] += W[64 features of this wave x 16*NKB] * act^T[16*NKB x 64 points]: three fp16 MFMAs
+// per product (W_lo*a_hi, W_hi*a_lo, W_hi*a_hi: small terms first), fp32 accumulate.
+// Weight fragments stream from global memory through a 2-deep register ring (one k-block = 4 loads in
+// flight behind the one being consumed); activation fragments come from the LDS images.
 template <int NKB>
-__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[2][CT], const h8 *Ahi, const h8 *Alo, const h8 *__restrict__ Wl,
+__device__ __forceinline__ void gemm_tile(f32x16 (&acc)[CT][2], const h8 *Ahi, const h8 *Alo, const h8 *__restrict__ Wl,
                                           int wave, int lane)
 {
+    static_assert(NKB % 2 == 0 && CT == 2, "ring depth / tile count");
     const int r = lane & 31, hh = lane >> 5;
-    const h8 *bp = Wl + (int64_t)wave * CT * NKB * 2 * 64 + lane;
-    h8 b_cur[CT][2], b_nxt[CT][2];
-#pragma unroll
-    for (int tn = 0; tn < CT; ++tn) { b_cur[tn][0] = bp[(int64_t)tn * NKB * 128]; b_cur[tn][1] = bp[(int64_t)tn * NKB * 128 + 64]; }
-#pragma unroll 2
-    for (int kb = 0; kb < NKB; ++kb) {
-        const int kn = kb + 1 < NKB ? kb + 1 : kb;
-#pragma unroll
-        for (int tn = 0; tn < CT; ++tn) {
-            b_nxt[tn][0] = bp[((int64_t)tn * NKB + kn) * 128];
-            b_nxt[tn][1] = bp[((int64_t)tn * NKB + kn) * 128 + 64];
-        }
-        const int u = kb * 2 + hh;
-        const int o0 = unit(u, r), o1 = unit(u, 32 + r);
-        const h8 ah0 = Ahi[o0], ah1 = Ahi[o1], al0 = Alo[o0], al1 = Alo[o1];
-#pragma unroll
-        for (int tn = 0; tn < CT; ++tn) {  // small terms first
-            acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al0, b_cur[tn][0], acc[0][tn], 0, 0, 0);
-            acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al1, b_cur[tn][0], acc[1][tn], 0, 0, 0);
-            acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, b_cur[tn][1], acc[0][tn], 0, 0, 0);
-            acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, b_cur[tn][1], acc[1][tn], 0, 0, 0);
-            acc[0][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah0, b_cur[tn][0], acc[0][tn], 0, 0, 0);
-            acc[1][tn] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah1, b_cur[tn][0], acc[1][tn], 0, 0, 0);
-        }
-#pragma unroll
-        for (int tn = 0; tn < CT; ++tn) { b_cur[tn][0] = b_nxt[tn][0]; b_cur[tn][1] = b_nxt[tn][1]; }
+    // per column tile: this lane's pointer into the packed layer block, advanced one k-block (2 KiB) per step
+    const char *wp0 = (const char *)(Wl + (int64_t)(wave * CT + 0) * NKB * 128 + lane);
+    const char *wp1 = (const char *)(Wl + (int64_t)(wave * CT + 1) * NKB * 128 + lane);
+    h8 w[2][CT][2];
+    wload<0>(w[0][0][0], wp0); wload<1024>(w[0][0][1], wp0); wload<0>(w[0][1][0], wp1); wload<1024>(w[0][1][1], wp1);
+#define DINER_F16_STEP(ST, LOADS, WAITN)                                                                        \
+    {                                                                                                           \
+        const int kb = kb0 + ST;                                                                                \
+        if (LOADS) { /* k-block kb+1 -> the other ring slot */                                                  \
+            wload<2048>(w[(ST + 1) & 1][0][0], wp0); wload<3072>(w[(ST + 1) & 1][0][1], wp0);                   \
+            wload<2048>(w[(ST + 1) & 1][1][0], wp1); wload<3072>(w[(ST + 1) & 1][1][1], wp1);                   \
+            wp0 += 2048; wp1 += 2048;                                                                           \
+        }                                                                                                       \
+        const int u = kb * 2 + hh, o0 = unit(u, r), o1 = unit(u, 32 + r);                                       \
+        const h8 ah0 = Ahi[o0], ah1 = Ahi[o1], al0 = Alo[o0], al1 = Alo[o1];                                    \
+        wwait<WAITN>(w[ST]);                                                                                    \
+        _Pragma("unroll") for (int tn = 0; tn < CT; ++tn) {                                                     \
+            acc[tn][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ST][tn][1], ah0, acc[tn][0], 0, 0, 0);         \
+            acc[tn][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ST][tn][1], ah1, acc[tn][1], 0, 0, 0);         \
+        }                                                                                                       \
+        _Pragma("unroll") for (int tn = 0; tn < CT; ++tn) {                                                     \
+            acc[tn][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ST][tn][0], al0, acc[tn][0], 0, 0, 0);         \
+            acc[tn][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ST][tn][0], al1, acc[tn][1], 0, 0, 0);         \
+        }                                                                                                       \
+        _Pragma("unroll") for (int tn = 0; tn < CT; ++tn) {                                                     \
+            acc[tn][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ST][tn][0], ah0, acc[tn][0], 0, 0, 0);         \
+            acc[tn][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(w[ST][tn][0], ah1, acc[tn][1], 0, 0, 0);         \
+        }                                                                                                       \
     }
+    int kb0 = 0;
+    for (; kb0 < NKB - 2; kb0 += 2) {
+        DINER_F16_STEP(0, true, 4) DINER_F16_STEP(1, true, 4)
+    }
+    DINER_F16_STEP(0, true, 4) DINER_F16_STEP(1, false, 0)  // last pair: the ring drains
+#undef DINER_F16_STEP
 }
 
-__device__ __forceinline__ void acc_set_bias(f32x16 (&acc)[2][CT], const float *__restrict__ bias, int wave, int lane)
+// Accumulator layout (transposed product): lane (c = l&31, h = l>>5), register i of acc[tn][tp] holds
+// feature n = 64*wave + 32*tn + 8*(i>>2) + 4*h + (i&3) of point 32*tp + c.
+template <bool ADD>
+__device__ __forceinline__ void acc_bias(f32x16 (&acc)[CT][2], const float *bias, int wave, int lane)
 {
+    const int h = lane >> 5;
 #pragma unroll
-    for (int tn = 0; tn < CT; ++tn) {
-        const float b = bias[wave * (32 * CT) + tn * 32 + (lane & 31)];
+    for (int tn = 0; tn < CT; ++tn)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[0][tn][i] = b; acc[1][tn][i] = b; }
-    }
-}
-__device__ __forceinline__ void acc_add_bias(f32x16 (&acc)[2][CT], const float *__restrict__ bias, int wave, int lane)
-{
+        for (int g = 0; g < 4; ++g) {
+            const f32x4 b = *(const f32x4 *)(bias + wave * (32 * CT) + tn * 32 + 8 * g + 4 * h);
 #pragma unroll
-    for (int tn = 0; tn < CT; ++tn) {
-        const float b = bias[wave * (32 * CT) + tn * 32 + (lane & 31)];
+            for (int tp = 0; tp < 2; ++tp)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) { acc[0][tn][i] += b; acc[1][tn][i] += b; }
-    }
+                for (int j = 0; j < 4; ++j) {
+                    if (ADD) acc[tn][tp][4 * g + j] += b[j];
+                    else acc[tn][tp][4 * g + j] = b[j];
+                }
+        }
 }
 
-// relu(acc) -> split -> LDS A images: this wave's 64 columns become k = 64w .. 64w+63 of the next layer.
-// Lane c holds column k = base + c; neighbouring lanes hold neighbouring k, so an even/odd lane pair
-// swaps one value per register pair (DPP quad_perm, no LDS) and each lane writes one packed (k, k+1)
-// dword per image.
-__device__ __forceinline__ float swap_xor1(float v)
+// relu(acc) -> split -> LDS images: registers 4g..4g+3 of a lane are features k..k+3 (k = 8u + 4h) of
+// one point: half of the 16-byte unit (u, point) of each image, one 8-byte store each.
+__device__ __forceinline__ void store_relu(const f32x16 (&acc)[CT][2], _Float16 *Ahi, _Float16 *Alo, int wave, int lane)
 {
-    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1 /*quad_perm [1,0,3,2]*/, 0xF, 0xF, true));
-}
-__device__ __forceinline__ void store_relu(const f32x16 (&acc)[2][CT], _Float16 *Ahi, _Float16 *Alo, int wave, int lane)
-{
-    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
     const int c = lane & 31, h = lane >> 5;
-    const bool odd = lane & 1;
 #pragma unroll
-    for (int tn = 0; tn < CT; ++tn) {
-        const int k = wave * (32 * CT) + tn * 32 + c, u = k >> 3, j0 = (k & 7) & ~1;
+    for (int tn = 0; tn < CT; ++tn)
 #pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+        for (int g = 0; g < 4; ++g) {
+            const int u = wave * (4 * CT) + tn * 4 + g;
 #pragma unroll
-            for (int i = 0; i < 16; i += 2) {
-                // even lane writes (k, k+1) of register i's row; odd lane writes (k-1, k) of register i+1's row
-                float a0 = acc[tm][tn][i], a1 = acc[tm][tn][i + 1];
-                asm volatile("" : "+v"(a0), "+v"(a1));  // keep the two extracts static (no dynamic vector index)
-                a0 = a0 > 0.0f ? a0 : 0.0f;
-                a1 = a1 > 0.0f ? a1 : 0.0f;
-                const float keep = odd ? a1 : a0, give = odd ? a0 : a1;
-                const float got = swap_xor1(give);
-                const float v0 = odd ? got : keep, v1 = odd ? keep : got;           // values at k even, k odd
-                const int row = tm * 32 + 8 * (i >> 2) + 4 * h + (i & 3) + (odd ? 1 : 0);  // C/D layout of the 32x32 MFMA
-                _Float16 h0, l0, h1, l1;
-                split(v0, h0, l0);
-                split(v1, h1, l1);
-                const int o = unit(u, row) * 8 + j0;
-                *(h2 *)(Ahi + o) = h2{h0, h1};
-                *(h2 *)(Alo + o) = h2{l0, l1};
+            for (int tp = 0; tp < 2; ++tp) {
+                h4 vh, vl;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[tn][tp][4 * g + j];
+                    _Float16 hi, lo;
+                    split(v > 0.0f ? v : 0.0f, hi, lo);
+                    vh[j] = hi;
+                    vl[j] = lo;
+                }
+                const int o = unit(u, tp * 32 + c) * 8 + 4 * h;
+                *(h4 *)(Ahi + o) = vh;
+                *(h4 *)(Alo + o) = vl;
             }
-    }
+        }
 }
 
 struct Tap {
@@ -192,195 +233,238 @@ struct Tap {
     float nw, ne, sw, se;    // weights; a tap outside the map has its weight forced to 0
 };
 
+// STAMP = diagnostic build (env DINER_F16_STAMP=1): per-phase s_memtime totals of workgroup 0 / wave 0
+// go to `dbg`; never used by the product path.
+enum { PH_GEOM, PH_GEMM, PH_GATHER, PH_STORE, PH_BIAS, PH_BARRIER, PH_VIEWSUM, PH_HEAD, PH_COUNT };
+template <bool STAMP>
 __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene s, const float *__restrict__ Wp,
                                                                      const float *__restrict__ rays,
                                                                      const float *__restrict__ zsamp, int64_t NR, int K,
-                                                                     float *__restrict__ rgbsigma)
+                                                                     int64_t tiles,
+                                                                     float *__restrict__ rgbsigma,
+                                                                     unsigned long long *__restrict__ dbg)
 {
-    __shared__ h8 lds[2 * UNITS + TILE_P * 2];  // A_hi | A_lo | one Tap per row (all LDS in ONE array)
+    unsigned long long t_prev = 0, t_acc[PH_COUNT] = {0};
+    if (STAMP) t_prev = __builtin_amdgcn_s_memtime();
+#define PHASE(ID)                                                        \
+    if (STAMP) {                                                         \
+        __builtin_amdgcn_sched_barrier(0);                               \
+        const unsigned long long t_now = __builtin_amdgcn_s_memtime();   \
+        __builtin_amdgcn_s_waitcnt(0xC07F);                              \
+        t_acc[ID] += t_now - t_prev;                                     \
+        t_prev = t_now;                                                  \
+        __builtin_amdgcn_sched_barrier(0);                               \
+    }
+#define BARRIER()        \
+    PHASE(cur_phase)     \
+    __syncthreads();     \
+    PHASE(PH_BARRIER)
+    int cur_phase = PH_GEOM;
+    (void)cur_phase;
+    __shared__ h8 lds[2 * UNITS + TILE_P * 2 + BIAS_FLOATS / 4];  // A_hi | A_lo | one Tap per row | biases (ONE array)
     h8 *Ahi8 = lds, *Alo8 = lds + UNITS;
     _Float16 *Ahi = (_Float16 *)Ahi8, *Alo = (_Float16 *)Alo8;
     Tap *taps = (Tap *)(lds + 2 * UNITS);
+    float *bias = (float *)(lds + 2 * UNITS + TILE_P * 2);  // all 14 bias vectors + lin_out's, staged once
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: lets weight bases live in SGPRs
     const int sb = blockIdx.y;
     const int64_t P = NR * (int64_t)K;
-    int64_t tile;
-    {   // XCD-aware tile order (bijective for any grid size)
-        const int64_t nwg = gridDim.x, b = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = b % 8;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
-    }
     const _Float16 *Wh = (const _Float16 *)Wp;
-    const float *bias = Wp + W_HALFS / 2;
-
-    const int row = tid & 63;
-    int64_t p = tile * TILE_P + row;
-    if (p > P - 1) p = P - 1;
-    const int64_t ray = p / K;
-    const float *rp = rays + ((int64_t)sb * NR + ray) * 8;
-    const float zz = zsamp[(int64_t)sb * P + p];
-    const float dwx = rp[3], dwy = rp[4], dwz = rp[5];
-    const float wx = rp[0] + zz * dwx, wy = rp[1] + zz * dwy, wz = rp[2] + zz * dwz;  // nerf_renderer.py:304
-
-    f32x16 x[2][CT], net[2][CT], xsum[2][CT];
-#pragma unroll
-    for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-        for (int tn = 0; tn < CT; ++tn)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) xsum[tm][tn][i] = 0.0f;
-
+    for (int i = threadIdx.x; i < BIAS_FLOATS; i += NWAVES * 64) bias[i] = (Wp + W_HALFS / 2)[i];
     const float sxl = ((float)s.w - s.feature_padding * 2.0f) / (float)s.w;  // image_encoder.py:113-114
     const float syl = ((float)s.h - s.feature_padding * 2.0f) / (float)s.h;
+    const int row = tid & 63;
 
-    for (int v = 0; v < s.NV; ++v) {
-        // ---- geometry + positional encodings -> A[:, 0:64] (55 real inputs); footprint -> taps -----
-        {
-            const View vw = load_view(s, sb, v);
-            float px, py, pz, u, w;
-            project(vw, s.image_w, s.image_h, wx, wy, wz, px, py, pz, u, w);   // pixelnerf.py:91-93,105-108
-            float dcx, dcy, dcz;
-            rotate(vw, dwx, dwy, dwz, dcx, dcy, dcz);                            // :99-101
-            const float4 *tex = (const float4 *)s.maps + ((int64_t)sb * s.NV + v) * s.H * s.W * 2;
-            const int ddx = safe_idx(__builtin_rintf(clipf(unnorm(u, (float)s.W / 2.0f), (float)(s.W - 1))), s.W);
-            const int ddy = safe_idx(__builtin_rintf(clipf(unnorm(w, (float)s.H / 2.0f), (float)(s.H - 1))), s.H);
-            const float delta = tex[((int64_t)ddy * s.W + ddx) * 2].w - pz;     // :114-115
-            const float half_pi = 1.5707963267948966f;
-            for (int e = wave * 8; e < wave * 8 + 8; ++e) {                      // input layout :128
-                float val;
-                if (e < 3) val = e == 0 ? px : e == 1 ? py : pz;
-                else if (e < 39) { const int j = (e - 3) / 3, i = (e - 3) % 3;    // positional_encoding.py:45-49
-                    val = sinf(__builtin_fmaf(i == 0 ? px : i == 1 ? py : pz, s.freq_factor * (float)(1 << (j >> 1)), (j & 1) ? half_pi : 0.0f)); }
-                else if (e < 42) val = e == 39 ? dcx : e == 40 ? dcy : dcz;
-                else if (e == 42) val = delta;
-                else if (e < 55) { const int j = e - 43;
-                    val = sinf(__builtin_fmaf(delta, s.freq_factor * (float)(1 << (j >> 1)), (j & 1) ? half_pi : 0.0f)); }
-                else val = 0.0f;
-                _Float16 hi, lo;
-                split(val * ACT_SCALE, hi, lo);
-                const int o = unit(e >> 3, row) * 8 + (e & 7);
-                Ahi[o] = hi;
-                Alo[o] = lo;
-            }
-            if (wave == 0) {  // bilinear / border footprint in the latent map (image_encoder.py:97-127)
-                const float ix = clipf(unnorm(u * sxl, (float)s.w / 2.0f), (float)(s.w - 1));
-                const float iy = clipf(unnorm(w * syl, (float)s.h / 2.0f), (float)(s.h - 1));
-                const float x0f = floorf(ix), y0f = floorf(iy);
-                const float fx = ix - x0f, ex = 1.0f - fx, fy = iy - y0f, ey = 1.0f - fy;
-                const int x0 = safe_idx(x0f, s.w), y0 = safe_idx(y0f, s.h);
-                const bool x1ok = x0 + 1 <= s.w - 1, y1ok = y0 + 1 <= s.h - 1;
-                const int x1 = x1ok ? x0 + 1 : x0, y1 = y1ok ? y0 + 1 : y0;
-                Tap t;
-                const int f4 = HID / 4;
-                t.o00 = (y0 * s.w + x0) * f4; t.o01 = (y0 * s.w + x1) * f4;
-                t.o10 = (y1 * s.w + x0) * f4; t.o11 = (y1 * s.w + x1) * f4;
-                t.nw = ey * ex; t.ne = x1ok ? ey * fx : 0.0f;
-                t.sw = y1ok ? fy * ex : 0.0f; t.se = (x1ok && y1ok) ? fy * fx : 0.0f;
-                taps[row] = t;
-            }
-        }
-        __syncthreads();
-        acc_set_bias(x, bias, wave, lane);
-        gemm_tile<NKB_IN>(x, Ahi8, Alo8, (const h8 *)(Wh + OFF_LIN_IN), wave, lane);   // resnetfc.py:139
-        __syncthreads();
+    // persistent workgroup: in round i the grid covers tiles [i*G, (i+1)*G); inside a round the
+    // workgroups that share an XCD (equal blockIdx % 8) take a contiguous run of tiles, so neighbouring
+    // samples/rays -- the same latent texels -- are gathered through one L2 (bijective for any G)
+    int64_t slot;
+    {
+        const int64_t nwg = gridDim.x, b = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = b % 8;
+        slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
+    }
+    for (int64_t tile = slot; tile < tiles; tile += gridDim.x) {
+        int64_t p = tile * TILE_P + row;
+        if (p > P - 1) p = P - 1;  // tail tile: duplicate the last point, masked at the store
+        const int64_t ray = p / K;
+        const float *rp = rays + ((int64_t)sb * NR + ray) * 8;
+        const float zz = zsamp[(int64_t)sb * P + p];
+        const float dwx = rp[3], dwy = rp[4], dwz = rp[5];
+        const float wx = rp[0] + zz * dwx, wy = rp[1] + zz * dwy, wz = rp[2] + zz * dwz;  // nerf_renderer.py:304
 
-        const f32x4 *lat = (const f32x4 *)s.latent + ((int64_t)sb * s.NV + v) * s.h * s.w * (HID / 4);
-        for (int b = 0; b < DINER_COMBINE_LAYER; ++b) {
-            // ---- z = bilinear latent of the 64 points -> A images (each wave gathers 8 rows);
-            //      lane l takes channels 8l..8l+7 = one 16-byte unit of each image
-#pragma unroll 2
-            for (int rr = 0; rr < TILE_P / NWAVES; ++rr) {
-                const int r = wave * (TILE_P / NWAVES) + rr;
-                const Tap t = taps[r];
-                h8 vh, vl;
+        f32x16 x[CT][2], net[CT][2], xsum[CT][2];
+        for (int v = 0; v < s.NV; ++v) {
+            // ---- geometry + positional encodings -> images[:, 0:64] (55 real inputs); footprint -> taps ----
+            {
+                const View vw = load_view(s, sb, v);
+                float px, py, pz, u, w;
+                project(vw, s.image_w, s.image_h, wx, wy, wz, px, py, pz, u, w);   // pixelnerf.py:91-93,105-108
+                float dcx, dcy, dcz;
+                rotate(vw, dwx, dwy, dwz, dcx, dcy, dcz);                            // :99-101
+                const float4 *tex = (const float4 *)s.maps + ((int64_t)sb * s.NV + v) * s.H * s.W * 2;
+                const int ddx = safe_idx(__builtin_rintf(clipf(unnorm(u, (float)s.W / 2.0f), (float)(s.W - 1))), s.W);
+                const int ddy = safe_idx(__builtin_rintf(clipf(unnorm(w, (float)s.H / 2.0f), (float)(s.H - 1))), s.H);
+                const float delta = tex[((int64_t)ddy * s.W + ddx) * 2].w - pz;     // :114-115
+                const float half_pi = 1.5707963267948966f;
+                for (int e = wave * 8; e < wave * 8 + 8; ++e) {                      // input layout :128
+                    float val;
+                    if (e < 3) val = e == 0 ? px : e == 1 ? py : pz;
+                    else if (e < 39) { const int j = (e - 3) / 3, i = (e - 3) % 3;    // positional_encoding.py:45-49
+                        val = sinf(__builtin_fmaf(i == 0 ? px : i == 1 ? py : pz, s.freq_factor * (float)(1 << (j >> 1)), (j & 1) ? half_pi : 0.0f)); }
+                    else if (e < 42) val = e == 39 ? dcx : e == 40 ? dcy : dcz;
+                    else if (e == 42) val = delta;
+                    else if (e < 55) { const int j = e - 43;
+                        val = sinf(__builtin_fmaf(delta, s.freq_factor * (float)(1 << (j >> 1)), (j & 1) ? half_pi : 0.0f)); }
+                    else val = 0.0f;
+                    _Float16 hi, lo;
+                    split(val * ACT_SCALE, hi, lo);
+                    const int o = unit(e >> 3, row) * 8 + (e & 7);
+                    Ahi[o] = hi;
+                    Alo[o] = lo;
+                }
+                if (wave == 0) {  // bilinear / border footprint in the latent map (image_encoder.py:97-127)
+                    const float ix = clipf(unnorm(u * sxl, (float)s.w / 2.0f), (float)(s.w - 1));
+                    const float iy = clipf(unnorm(w * syl, (float)s.h / 2.0f), (float)(s.h - 1));
+                    const float x0f = floorf(ix), y0f = floorf(iy);
+                    const float fx = ix - x0f, ex = 1.0f - fx, fy = iy - y0f, ey = 1.0f - fy;
+                    const int x0 = safe_idx(x0f, s.w), y0 = safe_idx(y0f, s.h);
+                    const bool x1ok = x0 + 1 <= s.w - 1, y1ok = y0 + 1 <= s.h - 1;
+                    const int x1 = x1ok ? x0 + 1 : x0, y1 = y1ok ? y0 + 1 : y0;
+                    Tap t;
+                    const int f4 = HID / 4;
+                    t.o00 = (y0 * s.w + x0) * f4; t.o01 = (y0 * s.w + x1) * f4;
+                    t.o10 = (y1 * s.w + x0) * f4; t.o11 = (y1 * s.w + x1) * f4;
+                    t.nw = ey * ex; t.ne = x1ok ? ey * fx : 0.0f;
+                    t.sw = y1ok ? fy * ex : 0.0f; t.se = (x1ok && y1ok) ? fy * fx : 0.0f;
+                    taps[row] = t;
+                }
+            }
+            cur_phase = PH_GEOM; BARRIER()
+            acc_bias<false>(x, bias, wave, lane);
+            PHASE(PH_BIAS)
+            gemm_tile<NKB_IN>(x, Ahi8, Alo8, (const h8 *)(Wh + OFF_LIN_IN), wave, lane);   // resnetfc.py:139
+            cur_phase = PH_GEMM; BARRIER()
+
+            const f32x4 *lat = (const f32x4 *)s.latent + ((int64_t)sb * s.NV + v) * s.h * s.w * (HID / 4);
+            for (int b = 0; b < DINER_COMBINE_LAYER; ++b) {
+                // ---- z = bilinear latent of the 64 points -> images (each wave gathers 8 rows);
+                //      lane l takes channels 8l..8l+7 = one 16-byte unit of each image
+                constexpr int GB = 2;  // rows per batch: GB*8 16-byte loads per lane in flight
+                for (int r0 = 0; r0 < TILE_P / NWAVES; r0 += GB) {
+                    f32x4 tex[GB][2][4];
+                    Tap t[GB];
 #pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const int q = 2 * lane + half;
-                    const f32x4 a = lat[t.o00 + q], bb = lat[t.o01 + q], c = lat[t.o10 + q], d = lat[t.o11 + q];
+                    for (int rr = 0; rr < GB; ++rr) {
+                        t[rr] = taps[wave * (TILE_P / NWAVES) + r0 + rr];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {  // ATen's accumulation order nw,ne,sw,se with contracted FMAs
-                        const float o = __builtin_fmaf(d[i], t.se, __builtin_fmaf(c[i], t.sw, __builtin_fmaf(bb[i], t.ne, a[i] * t.nw)));
-                        _Float16 hi, lo;
-                        split(o * ACT_SCALE, hi, lo);
-                        vh[half * 4 + i] = hi;
-                        vl[half * 4 + i] = lo;
+                        for (int half = 0; half < 2; ++half) {
+                            const int q = 2 * lane + half;
+                            tex[rr][half][0] = lat[t[rr].o00 + q]; tex[rr][half][1] = lat[t[rr].o01 + q];
+                            tex[rr][half][2] = lat[t[rr].o10 + q]; tex[rr][half][3] = lat[t[rr].o11 + q];
+                        }
+                    }
+#pragma unroll
+                    for (int rr = 0; rr < GB; ++rr) {
+                        h8 vh, vl;
+#pragma unroll
+                        for (int half = 0; half < 2; ++half)
+#pragma unroll
+                            for (int i = 0; i < 4; ++i) {  // ATen's accumulation order nw,ne,sw,se with contracted FMAs
+                                const float o = __builtin_fmaf(tex[rr][half][3][i], t[rr].se, __builtin_fmaf(tex[rr][half][2][i], t[rr].sw,
+                                                __builtin_fmaf(tex[rr][half][1][i], t[rr].ne, tex[rr][half][0][i] * t[rr].nw)));
+                                _Float16 hi, lo;
+                                split(o * ACT_SCALE, hi, lo);
+                                vh[half * 4 + i] = hi;
+                                vl[half * 4 + i] = lo;
+                            }
+                        const int o = unit(lane, wave * (TILE_P / NWAVES) + r0 + rr);
+                        Ahi8[o] = vh;
+                        Alo8[o] = vl;
                     }
                 }
-                const int o = unit(lane, r);
-                Ahi8[o] = vh;
-                Alo8[o] = vl;
+                cur_phase = PH_GATHER; BARRIER()
+                acc_bias<true>(x, bias + 512 * (1 + b), wave, lane);                         // :152-153 x = x + lin_z(z)
+                PHASE(PH_BIAS)
+                gemm_tile<NKB_FULL>(x, Ahi8, Alo8, (const h8 *)(Wh + OFF_LIN_Z + b * W_FULL), wave, lane);
+                cur_phase = PH_GEMM; BARRIER()
+                store_relu(x, Ahi, Alo, wave, lane);                                        // :62 fc_0(relu(x))
+                cur_phase = PH_STORE; BARRIER()
+                acc_bias<false>(net, bias + 512 * (4 + b), wave, lane);
+                PHASE(PH_BIAS)
+                gemm_tile<NKB_FULL>(net, Ahi8, Alo8, (const h8 *)(Wh + OFF_FC0 + b * W_FULL), wave, lane);
+                cur_phase = PH_GEMM; BARRIER()
+                store_relu(net, Ahi, Alo, wave, lane);                                      // :63 fc_1(relu(net))
+                cur_phase = PH_STORE; BARRIER()
+                acc_bias<true>(x, bias + 512 * (9 + b), wave, lane);                         // :69 x + dx
+                PHASE(PH_BIAS)
+                gemm_tile<NKB_FULL>(x, Ahi8, Alo8, (const h8 *)(Wh + OFF_FC1 + b * W_FULL), wave, lane);
+                cur_phase = PH_GEMM; BARRIER()
             }
-            __syncthreads();
-            acc_add_bias(x, bias + 512 * (1 + b), wave, lane);                          // :152-153 x = x + lin_z(z)
-            gemm_tile<NKB_FULL>(x, Ahi8, Alo8, (const h8 *)(Wh + OFF_LIN_Z + b * W_FULL), wave, lane);
-            __syncthreads();
-            store_relu(x, Ahi, Alo, wave, lane);                                        // :62 fc_0(relu(x))
-            __syncthreads();
-            acc_set_bias(net, bias + 512 * (4 + b), wave, lane);
-            gemm_tile<NKB_FULL>(net, Ahi8, Alo8, (const h8 *)(Wh + OFF_FC0 + b * W_FULL), wave, lane);
-            __syncthreads();
-            store_relu(net, Ahi, Alo, wave, lane);                                      // :63 fc_1(relu(net))
-            __syncthreads();
-            acc_add_bias(x, bias + 512 * (9 + b), wave, lane);                          // :69 x + dx
-            gemm_tile<NKB_FULL>(x, Ahi8, Alo8, (const h8 *)(Wh + OFF_FC1 + b * W_FULL), wave, lane);
-            __syncthreads();
-        }
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
-#pragma unroll
-            for (int tn = 0; tn < CT; ++tn) xsum[tm][tn] += x[tm][tn];                  // :146-149
-    }
-    {
-        const float nv = (float)s.NV;
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm)
+            // ---- running sum over views (resnetfc.py:146-149) ----------------------------------------
 #pragma unroll
             for (int tn = 0; tn < CT; ++tn)
 #pragma unroll
-                for (int i = 0; i < 16; ++i) xsum[tm][tn][i] = xsum[tm][tn][i] / nv;  // combine(): mean over views
-    }
-    for (int b = DINER_COMBINE_LAYER; b < DINER_N_BLOCKS; ++b) {
-        store_relu(xsum, Ahi, Alo, wave, lane);
-        __syncthreads();
-        acc_set_bias(net, bias + 512 * (4 + b), wave, lane);
-        gemm_tile<NKB_FULL>(net, Ahi8, Alo8, (const h8 *)(Wh + OFF_FC0 + b * W_FULL), wave, lane);
-        __syncthreads();
-        store_relu(net, Ahi, Alo, wave, lane);
-        __syncthreads();
-        acc_add_bias(xsum, bias + 512 * (9 + b), wave, lane);
-        gemm_tile<NKB_FULL>(xsum, Ahi8, Alo8, (const h8 *)(Wh + OFF_FC1 + b * W_FULL), wave, lane);
-        __syncthreads();
-    }
-    store_relu(xsum, Ahi, Alo, wave, lane);                                             // :158 lin_out(relu(x))
-    __syncthreads();
-    if (wave < 2) {  // lin_out: one 32-column tile (4 real outputs), wave w = rows 32w..32w+31
-        f32x16 o;
-        const float bo = bias[14 * 512 + (lane & 31)];
-#pragma unroll
-        for (int i = 0; i < 16; ++i) o[i] = bo;
-        const int r = lane & 31, hh = lane >> 5;
-        const h8 *bp = (const h8 *)(Wh + OFF_LIN_OUT) + lane;
-#pragma unroll 4
-        for (int kb = 0; kb < NKB_FULL; ++kb) {
-            const int oa = unit(kb * 2 + hh, wave * 32 + r);
-            const h8 ah = Ahi8[oa], al = Alo8[oa], bh = bp[kb * 128], bl = bp[kb * 128 + 64];
-            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, o, 0, 0, 0);
-            o = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, o, 0, 0, 0);
+                for (int tp = 0; tp < 2; ++tp) xsum[tn][tp] = (v == 0) ? x[tn][tp] : xsum[tn][tp] + x[tn][tp];
+            PHASE(PH_VIEWSUM)
         }
-        const int c = lane & 31, h = lane >> 5;
-        if (c < 4) {
+        {
+            const float nv = (float)s.NV;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int rr = wave * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
-                const int64_t pp = tile * TILE_P + rr;
-                if (pp < P) {
-                    const float val = o[i] * (1.0f / ACT_SCALE);                       // pixelnerf.py:139-143
-                    rgbsigma[((int64_t)sb * P + pp) * 4 + c] = c < 3 ? 1.0f / (1.0f + expf(-val)) : (val > 0.0f ? val : 0.0f);
+            for (int tn = 0; tn < CT; ++tn)
+#pragma unroll
+                for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) x[tn][tp][i] = xsum[tn][tp][i] / nv;  // combine(): mean over views
+        }
+        for (int b = DINER_COMBINE_LAYER; b < DINER_N_BLOCKS; ++b) {
+            store_relu(x, Ahi, Alo, wave, lane);
+            cur_phase = PH_STORE; BARRIER()
+            acc_bias<false>(net, bias + 512 * (4 + b), wave, lane);
+            PHASE(PH_BIAS)
+            gemm_tile<NKB_FULL>(net, Ahi8, Alo8, (const h8 *)(Wh + OFF_FC0 + b * W_FULL), wave, lane);
+            cur_phase = PH_GEMM; BARRIER()
+            store_relu(net, Ahi, Alo, wave, lane);
+            cur_phase = PH_STORE; BARRIER()
+            acc_bias<true>(x, bias + 512 * (9 + b), wave, lane);
+            PHASE(PH_BIAS)
+            gemm_tile<NKB_FULL>(x, Ahi8, Alo8, (const h8 *)(Wh + OFF_FC1 + b * W_FULL), wave, lane);
+            cur_phase = PH_GEMM; BARRIER()
+        }
+        store_relu(x, Ahi, Alo, wave, lane);                                                // :158 lin_out(relu(x))
+        cur_phase = PH_STORE; BARRIER()
+        if (wave < 2) {  // lin_out: one 32-feature tile (4 real outputs), wave w = points 32w..32w+31
+            f32x16 o;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[i] = 0.0f;
+            const int r = lane & 31, hh = lane >> 5;
+            const h8 *bp = (const h8 *)(Wh + OFF_LIN_OUT) + lane;
+#pragma unroll 4
+            for (int kb = 0; kb < NKB_FULL; ++kb) {
+                const int oa = unit(kb * 2 + hh, wave * 32 + r);
+                const h8 ah = Ahi8[oa], al = Alo8[oa], bh = bp[kb * 128], bl = bp[kb * 128 + 64];
+                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(bl, ah, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, al, o, 0, 0, 0);
+                o = __builtin_amdgcn_mfma_f32_32x32x16_f16(bh, ah, o, 0, 0, 0);
+            }
+            const int64_t pp = tile * TILE_P + wave * 32 + r;
+            if (hh == 0 && pp < P) {  // registers 0..3 of the h=0 half are outputs 0..3 of point r
+                f32x4 out;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float val = (o[j] + bias[14 * 512 + j]) * (1.0f / ACT_SCALE);       // pixelnerf.py:139-143
+                    out[j] = j < 3 ? 1.0f / (1.0f + expf(-val)) : (val > 0.0f ? val : 0.0f);
                 }
+                *(f32x4 *)(rgbsigma + ((int64_t)sb * P + pp) * 4) = out;
             }
         }
+        cur_phase = PH_HEAD; BARRIER()  // the images are rewritten by the next tile's geometry phase
     }
+    if (STAMP && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0)
+        for (int i = 0; i < PH_COUNT; ++i) dbg[wave * PH_COUNT + i] = t_acc[i];
+#undef PHASE
+#undef BARRIER
 }
 
 }  // namespace f16x3
@@ -395,6 +479,18 @@ int launch_pack_mlp_f16(const DinerMlpRaw &raw, float *out, hipStream_t st)
     return check_launch("f16x3::pack_kernel");
 }
 
+// persistent grid: one workgroup per CU (the 130-KiB LDS image admits exactly one)
+static int f16_grid_limit()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
 int launch_points_mlp_f16(const DinerScene &s, const float *mlp_packed, const float *rays, const float *z, int64_t NR,
                           int K, float *rgbsigma, hipStream_t st)
 {
@@ -404,9 +500,29 @@ int launch_points_mlp_f16(const DinerScene &s, const float *mlp_packed, const fl
     if (s.C != DINER_D_LATENT) { set_error("render_points: latent channels C=%d unsupported (need %d)", s.C, DINER_D_LATENT); return DINER_E_UNSUPPORTED; }
     if (s.num_freqs != 6) { set_error("render_points: num_freqs=%d unsupported (need 6)", s.num_freqs); return DINER_E_UNSUPPORTED; }
     const int64_t tiles = (P + TILE_P - 1) / TILE_P;
-    if (tiles > 0x7fffffffLL) { set_error("render_points: too many points (%lld)", (long long)P); return DINER_E_INVALID; }
-    hipLaunchKernelGGL(points_mlp_f16_kernel, dim3((unsigned)tiles, (unsigned)s.SB), dim3(NWAVES * 64), 0, st, s, mlp_packed,
-                       rays, z, NR, K, rgbsigma);
+    const int64_t grid = tiles < f16_grid_limit() ? tiles : f16_grid_limit();
+    static const bool stamp = getenv("DINER_F16_STAMP") != nullptr;  // diagnostics only
+    if (stamp) {
+        static unsigned long long *dbg = nullptr;
+        if (!dbg && hipMalloc(&dbg, NWAVES * PH_COUNT * sizeof(unsigned long long)) != hipSuccess) return DINER_E_LAUNCH;
+        (void)hipMemsetAsync(dbg, 0, NWAVES * PH_COUNT * sizeof(unsigned long long), st);
+        hipLaunchKernelGGL(points_mlp_f16_kernel<true>, dim3((unsigned)grid, (unsigned)s.SB), dim3(NWAVES * 64), 0, st, s,
+                           mlp_packed, rays, z, NR, K, tiles, rgbsigma, dbg);
+        unsigned long long h[NWAVES * PH_COUNT];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
+        static const char *names[PH_COUNT] = {"geom", "gemm", "gather", "store", "bias", "barrier", "viewsum", "head"};
+        for (int w = 0; w < NWAVES; ++w) {
+            unsigned long long tot = 0;
+            for (int i = 0; i < PH_COUNT; ++i) tot += h[w * PH_COUNT + i];
+            fprintf(stderr, "[f16 stamp] wg0 wave%d:", w);
+            for (int i = 0; i < PH_COUNT; ++i) fprintf(stderr, " %s=%.1f%%", names[i], 100.0 * (double)h[w * PH_COUNT + i] / (double)(tot ? tot : 1));
+            fprintf(stderr, " total=%llu\n", tot);
+        }
+        return check_launch("points_mlp_f16_kernel<stamp>");
+    }
+    hipLaunchKernelGGL(points_mlp_f16_kernel<false>, dim3((unsigned)grid, (unsigned)s.SB), dim3(NWAVES * 64), 0, st, s,
+                       mlp_packed, rays, z, NR, K, tiles, rgbsigma, (unsigned long long *)nullptr);
     return check_launch("points_mlp_f16_kernel");
 }
 

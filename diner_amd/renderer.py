@@ -269,7 +269,8 @@ class NeRFRendererDGS(torch.nn.Module):
         assert SB == sc.SB  # pixelnerf.py:68
         packed = self._mlp(model)
         out = torch.empty((SB, NR, K, 4), dtype=torch.float32, device=r.device)
-        check(_lib.lib().diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, _lib.PRECISIONS[self.precision],
+        prec = _lib.PRECISIONS[self.precision]
+        check(_lib.lib().diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, prec,
                                              _ptr(out), _stream(r.device)),
               "diner_render_points")
         return out
@@ -329,11 +330,12 @@ class NeRFRendererDGS(torch.nn.Module):
                 u_c = n_g = u_f = None
                 if noise is not None:
                     u_c, n_g, u_f = [None if t is None else _f32c(t).to(dev) for t in noise]
+                prec = _lib.PRECISIONS[self.precision]
                 ws = torch.empty(int(_lib.lib().diner_render_workspace_floats(SB, NR, K)), dtype=torch.float32, device=dev)
                 L, st, seed = _lib.lib(), _stream(dev), self._next_seed()
                 if self.stage_events is None:
                     check(L.diner_render(C.byref(sc), _ptr(packed), _ptr(r), NR, C.byref(cfg), int(bool(self.white_bkgd)),
-                                         _lib.PRECISIONS[self.precision], _ptr(u_c), _ptr(n_g), _ptr(u_f), seed, _ptr(ws), _ptr(rgb), _ptr(depth),
+                                         prec, _ptr(u_c), _ptr(n_g), _ptr(u_f), seed, _ptr(ws), _ptr(rgb), _ptr(depth),
                                          _ptr(weights), st), "diner_render")
                 else:
                     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
@@ -342,7 +344,7 @@ class NeRFRendererDGS(torch.nn.Module):
                     check(L.diner_sample_depthguided(C.byref(sc), _ptr(r), NR, C.byref(cfg), _ptr(u_c), _ptr(n_g), _ptr(u_f),
                                                      None, seed, _ptr(z), None, None, st), "diner_sample_depthguided")
                     ev[1].record()
-                    check(L.diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, _lib.PRECISIONS[self.precision],
+                    check(L.diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, prec,
                                                 _ptr(c), st),
                           "diner_render_points")
                     ev[2].record()
