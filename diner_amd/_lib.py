@@ -25,7 +25,7 @@ class DinerScene(C.Structure):
                 ("h", C.c_int32), ("w", C.c_int32), ("C", C.c_int32), ("num_freqs", C.c_int32),
                 ("image_w", C.c_float), ("image_h", C.c_float), ("feature_padding", C.c_float),
                 ("freq_factor", C.c_float),
-                ("poses", _FP), ("focal", _FP), ("c", _FP), ("maps", _FP), ("latent", _FP)]
+                ("poses", _FP), ("focal", _FP), ("c", _FP), ("maps", _FP), ("latent", _FP), ("linz_maps", _FP)]
 
 
 class DinerMlpRaw(C.Structure):
@@ -50,6 +50,7 @@ SYMBOLS = {
     "diner_pack_latent": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "diner_mlp_packed_floats": (_I64, []),
     "diner_pack_mlp": (C.c_int, [C.POINTER(DinerMlpRaw), _P, _P]),
+    "diner_pack_linz_maps": (C.c_int, [_P, _I64, _I32, _I32, _P, _P, _P]),
     "diner_sample_coarse": (C.c_int, [_P, _I64, _I32, _P, _U64, _P, _P]),
     "diner_sample_depthguided": (C.c_int, [C.POINTER(DinerScene), _P, _I64, C.POINTER(DinerSamplerCfg),
                                            _P, _P, _P, _P, _U64, _P, _P, _P, _P]),

@@ -32,6 +32,7 @@ int launch_pack_maps(const float *, const float *, const float *, int64_t, int, 
 int launch_pack_latent(const float *, int64_t, int, int, int, float *, hipStream_t);
 int launch_pack_mlp(const DinerMlpRaw &, float *, hipStream_t);
 int64_t mlp_packed_floats();
+int launch_linz_maps(const float *, int64_t, const float *, float *, hipStream_t);
 int launch_sampler(const DinerScene &, const float *, int64_t, const DinerSamplerCfg &, const float *, const float *,
                    const float *, const float *, uint64_t, float *, float *, float *, hipStream_t);
 int launch_sample_coarse(const float *, int64_t, int, const float *, uint64_t, float *, hipStream_t);
@@ -105,6 +106,14 @@ int diner_pack_mlp(const DinerMlpRaw *raw, float *packed_out, void *stream)
     const int rc = launch_pack_mlp(*raw, packed_out, (hipStream_t)stream);
     if (rc) return rc;
     return launch_pack_mlp_f16(*raw, packed_out + mlp_packed_floats(), (hipStream_t)stream);
+}
+
+int diner_pack_linz_maps(const float *latent_packed, int64_t N, int32_t h, int32_t w, const float *mlp_packed, float *out,
+                         void *stream)
+{
+    if (!latent_packed || !mlp_packed || !out) return bad("pack_linz_maps: NULL pointer");
+    if (N < 0 || h <= 0 || w <= 0) return bad("pack_linz_maps: bad size");
+    return launch_linz_maps(latent_packed, N * h * w, mlp_packed, out, (hipStream_t)stream);
 }
 
 int diner_sample_coarse(const float *rays, int64_t N, int32_t NC, const float *u_coarse, uint64_t seed, float *z_out,

@@ -346,6 +346,63 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_kernel(DinerScene s, c
     }
 }
 
+// ---- once per encode(): G_b = lin_z[b](latent) as three extra feature maps ------------------------
+// lin_z is linear and SpatialEncoder.index is a convex combination of 4 texels, so
+//   lin_z[b](bilerp(F)(uv)) = bilerp(lin_z[b](F))(uv)            (resnetfc.py:152, image_encoder.py:97-127)
+// up to fp32 rounding.  Evaluating lin_z on the latent MAP once per encode (NV*h*w rows instead of
+// NV * points rows per frame: 0.64 TFLOP instead of 211 TFLOP at the headline config) removes three of
+// the nine per-view GEMMs from the per-point kernel, which then adds bilerp(G_b) straight into its
+// accumulators.  Exact fp32 MFMA here (bit-identical to an fmaf chain), bias included.
+// in: latent [N,h,w,512] NHWC rows; out: [3][N,h,w,512].
+__global__ __launch_bounds__(NWAVES * 64) void linz_maps_kernel(const float *__restrict__ latent, int64_t rows,
+                                                                const float *__restrict__ Wp, float *__restrict__ out)
+{
+    __shared__ f32x4 lds[A_F4];
+    f32x4 *A4 = lds;
+    float *A = (float *)lds;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t row0 = (int64_t)blockIdx.x * TILE_P;
+    // stage 64 latent rows (2 KiB each) into the A image
+    for (int rr = 0; rr < TILE_P / NWAVES; ++rr) {
+        const int r = wave * (TILE_P / NWAVES) + rr;
+        const int64_t gr = row0 + r < rows ? row0 + r : rows - 1;
+        const f32x4 *src = (const f32x4 *)(latent + gr * HID);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int q = lane + 64 * half;
+            const f32x4 v = src[q];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) A[a_off(r, 4 * q + i)] = v[i];
+        }
+    }
+    __syncthreads();
+    const float *bias = Wp + OFF_BIAS;
+    for (int b = 0; b < DINER_COMBINE_LAYER; ++b) {
+        f32x16 acc[2][CT];
+        acc_set_bias(acc, bias + 512 * bias_slot_lin_z(b), wave, lane);
+        gemm_tile<NJB_FULL>(acc, A4, (const f32x4 *)(Wp + OFF_LIN_Z + b * W_FULL), wave, lane);
+        float *dst = out + (int64_t)b * rows * HID;
+        const int c = lane & 31, h = lane >> 5;
+#pragma unroll
+        for (int tn = 0; tn < CT; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < 2; ++tm)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t gr = row0 + tm * 32 + 8 * (i >> 2) + 4 * h + (i & 3);
+                    if (gr < rows) dst[gr * HID + wave * (32 * CT) + tn * 32 + c] = acc[tm][tn][i];
+                }
+    }
+}
+
+int launch_linz_maps(const float *latent_nhwc, int64_t rows, const float *mlp_packed, float *out, hipStream_t st)
+{
+    if (rows == 0) return DINER_OK;
+    hipLaunchKernelGGL(linz_maps_kernel, dim3((unsigned)((rows + TILE_P - 1) / TILE_P)), dim3(NWAVES * 64), 0, st, latent_nhwc,
+                       rows, mlp_packed, out);
+    return check_launch("linz_maps_kernel");
+}
+
 int launch_points_mlp(const DinerScene &s, const float *mlp_packed, const float *rays, const float *z, int64_t NR,
                       int K, float *rgbsigma, hipStream_t st)
 {

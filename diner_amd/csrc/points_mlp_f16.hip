@@ -236,7 +236,9 @@ struct Tap {
 // STAMP = diagnostic build (env DINER_F16_STAMP=1): per-phase s_memtime totals of workgroup 0 / wave 0
 // go to `dbg`; never used by the product path.
 enum { PH_GEOM, PH_GEMM, PH_GATHER, PH_STORE, PH_BIAS, PH_BARRIER, PH_VIEWSUM, PH_HEAD, PH_COUNT };
-template <bool STAMP>
+// LINZ: lin_z[b](z) comes from the pre-multiplied feature maps s.linz_maps (diner_pack_linz_maps) as a
+// bilinear gather-add into the accumulators instead of a gather + GEMM per block.
+template <bool STAMP, bool LINZ>
 __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene s, const float *__restrict__ Wp,
                                                                      const float *__restrict__ rays,
                                                                      const float *__restrict__ zsamp, int64_t NR, int K,
@@ -349,46 +351,73 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
 
             const f32x4 *lat = (const f32x4 *)s.latent + ((int64_t)sb * s.NV + v) * s.h * s.w * (HID / 4);
             for (int b = 0; b < DINER_COMBINE_LAYER; ++b) {
-                // ---- z = bilinear latent of the 64 points -> images (each wave gathers 8 rows);
-                //      lane l takes channels 8l..8l+7 = one 16-byte unit of each image
-                constexpr int GB = 2;  // rows per batch: GB*8 16-byte loads per lane in flight
-                for (int r0 = 0; r0 < TILE_P / NWAVES; r0 += GB) {
-                    f32x4 tex[GB][2][4];
-                    Tap t[GB];
+                if (LINZ) {
+                    // ---- x += lin_z[b](z) = bilerp(G_b)(uv) (resnetfc.py:152-153): gather-add in the accumulator
+                    //      layout -- a lane owns 4 consecutive features (one float4 per tap) of its two points
+                    const f32x4 *G = (const f32x4 *)s.linz_maps + (((int64_t)b * s.SB + sb) * s.NV + v) * s.h * s.w * (HID / 4);
+                    const int c = lane & 31, h = lane >> 5;
 #pragma unroll
-                    for (int rr = 0; rr < GB; ++rr) {
-                        t[rr] = taps[wave * (TILE_P / NWAVES) + r0 + rr];
+                    for (int tp = 0; tp < 2; ++tp) {
+                        const Tap t = taps[32 * tp + c];
+                        const float nw = t.nw * ACT_SCALE, ne = t.ne * ACT_SCALE, sw = t.sw * ACT_SCALE, se = t.se * ACT_SCALE;
 #pragma unroll
-                        for (int half = 0; half < 2; ++half) {
-                            const int q = 2 * lane + half;
-                            tex[rr][half][0] = lat[t[rr].o00 + q]; tex[rr][half][1] = lat[t[rr].o01 + q];
-                            tex[rr][half][2] = lat[t[rr].o10 + q]; tex[rr][half][3] = lat[t[rr].o11 + q];
+                        for (int tn = 0; tn < CT; ++tn) {
+                            f32x4 ta[4], tb[4], tc[4], td[4];
+#pragma unroll
+                            for (int g = 0; g < 4; ++g) {
+                                const int q = wave * (8 * CT) + tn * 8 + 2 * g + h;
+                                ta[g] = G[t.o00 + q]; tb[g] = G[t.o01 + q]; tc[g] = G[t.o10 + q]; td[g] = G[t.o11 + q];
+                            }
+#pragma unroll
+                            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    x[tn][tp][4 * g + j] += __builtin_fmaf(td[g][j], se, __builtin_fmaf(tc[g][j], sw, __builtin_fmaf(tb[g][j], ne, ta[g][j] * nw)));
                         }
                     }
-#pragma unroll
-                    for (int rr = 0; rr < GB; ++rr) {
-                        h8 vh, vl;
-#pragma unroll
-                        for (int half = 0; half < 2; ++half)
-#pragma unroll
-                            for (int i = 0; i < 4; ++i) {  // ATen's accumulation order nw,ne,sw,se with contracted FMAs
-                                const float o = __builtin_fmaf(tex[rr][half][3][i], t[rr].se, __builtin_fmaf(tex[rr][half][2][i], t[rr].sw,
-                                                __builtin_fmaf(tex[rr][half][1][i], t[rr].ne, tex[rr][half][0][i] * t[rr].nw)));
-                                _Float16 hi, lo;
-                                split(o * ACT_SCALE, hi, lo);
-                                vh[half * 4 + i] = hi;
-                                vl[half * 4 + i] = lo;
+                    PHASE(PH_GATHER)
+                } else {
+                // ---- z = bilinear latent of the 64 points -> images (each wave gathers 8 rows);
+                    //      lane l takes channels 8l..8l+7 = one 16-byte unit of each image
+                    constexpr int GB = 2;  // rows per batch: GB*8 16-byte loads per lane in flight
+                    for (int r0 = 0; r0 < TILE_P / NWAVES; r0 += GB) {
+                        f32x4 tex[GB][2][4];
+                        Tap t[GB];
+    #pragma unroll
+                        for (int rr = 0; rr < GB; ++rr) {
+                            t[rr] = taps[wave * (TILE_P / NWAVES) + r0 + rr];
+    #pragma unroll
+                            for (int half = 0; half < 2; ++half) {
+                                const int q = 2 * lane + half;
+                                tex[rr][half][0] = lat[t[rr].o00 + q]; tex[rr][half][1] = lat[t[rr].o01 + q];
+                                tex[rr][half][2] = lat[t[rr].o10 + q]; tex[rr][half][3] = lat[t[rr].o11 + q];
                             }
-                        const int o = unit(lane, wave * (TILE_P / NWAVES) + r0 + rr);
-                        Ahi8[o] = vh;
-                        Alo8[o] = vl;
+                        }
+    #pragma unroll
+                        for (int rr = 0; rr < GB; ++rr) {
+                            h8 vh, vl;
+    #pragma unroll
+                            for (int half = 0; half < 2; ++half)
+    #pragma unroll
+                                for (int i = 0; i < 4; ++i) {  // ATen's accumulation order nw,ne,sw,se with contracted FMAs
+                                    const float o = __builtin_fmaf(tex[rr][half][3][i], t[rr].se, __builtin_fmaf(tex[rr][half][2][i], t[rr].sw,
+                                                    __builtin_fmaf(tex[rr][half][1][i], t[rr].ne, tex[rr][half][0][i] * t[rr].nw)));
+                                    _Float16 hi, lo;
+                                    split(o * ACT_SCALE, hi, lo);
+                                    vh[half * 4 + i] = hi;
+                                    vl[half * 4 + i] = lo;
+                                }
+                            const int o = unit(lane, wave * (TILE_P / NWAVES) + r0 + rr);
+                            Ahi8[o] = vh;
+                            Alo8[o] = vl;
+                        }
                     }
+                    cur_phase = PH_GATHER; BARRIER()
+                    acc_bias<true>(x, bias + 512 * (1 + b), wave, lane);                         // :152-153 x = x + lin_z(z)
+                    PHASE(PH_BIAS)
+                    gemm_tile<NKB_FULL>(x, Ahi8, Alo8, (const h8 *)(Wh + OFF_LIN_Z + b * W_FULL), wave, lane);
+                    cur_phase = PH_GEMM; BARRIER()
                 }
-                cur_phase = PH_GATHER; BARRIER()
-                acc_bias<true>(x, bias + 512 * (1 + b), wave, lane);                         // :152-153 x = x + lin_z(z)
-                PHASE(PH_BIAS)
-                gemm_tile<NKB_FULL>(x, Ahi8, Alo8, (const h8 *)(Wh + OFF_LIN_Z + b * W_FULL), wave, lane);
-                cur_phase = PH_GEMM; BARRIER()
                 store_relu(x, Ahi, Alo, wave, lane);                                        // :62 fc_0(relu(x))
                 cur_phase = PH_STORE; BARRIER()
                 acc_bias<false>(net, bias + 512 * (4 + b), wave, lane);
@@ -502,11 +531,11 @@ int launch_points_mlp_f16(const DinerScene &s, const float *mlp_packed, const fl
     const int64_t tiles = (P + TILE_P - 1) / TILE_P;
     const int64_t grid = tiles < f16_grid_limit() ? tiles : f16_grid_limit();
     static const bool stamp = getenv("DINER_F16_STAMP") != nullptr;  // diagnostics only
-    if (stamp) {
+    if (stamp && s.linz_maps) {
         static unsigned long long *dbg = nullptr;
         if (!dbg && hipMalloc(&dbg, NWAVES * PH_COUNT * sizeof(unsigned long long)) != hipSuccess) return DINER_E_LAUNCH;
         (void)hipMemsetAsync(dbg, 0, NWAVES * PH_COUNT * sizeof(unsigned long long), st);
-        hipLaunchKernelGGL(points_mlp_f16_kernel<true>, dim3((unsigned)grid, (unsigned)s.SB), dim3(NWAVES * 64), 0, st, s,
+        hipLaunchKernelGGL((points_mlp_f16_kernel<true, true>), dim3((unsigned)grid, (unsigned)s.SB), dim3(NWAVES * 64), 0, st, s,
                            mlp_packed, rays, z, NR, K, tiles, rgbsigma, dbg);
         unsigned long long h[NWAVES * PH_COUNT];
         (void)hipStreamSynchronize(st);
@@ -521,8 +550,12 @@ int launch_points_mlp_f16(const DinerScene &s, const float *mlp_packed, const fl
         }
         return check_launch("points_mlp_f16_kernel<stamp>");
     }
-    hipLaunchKernelGGL(points_mlp_f16_kernel<false>, dim3((unsigned)grid, (unsigned)s.SB), dim3(NWAVES * 64), 0, st, s,
-                       mlp_packed, rays, z, NR, K, tiles, rgbsigma, (unsigned long long *)nullptr);
+    if (s.linz_maps)
+        hipLaunchKernelGGL((points_mlp_f16_kernel<false, true>), dim3((unsigned)grid, (unsigned)s.SB), dim3(NWAVES * 64), 0, st, s,
+                           mlp_packed, rays, z, NR, K, tiles, rgbsigma, (unsigned long long *)nullptr);
+    else
+        hipLaunchKernelGGL((points_mlp_f16_kernel<false, false>), dim3((unsigned)grid, (unsigned)s.SB), dim3(NWAVES * 64), 0, st, s,
+                           mlp_packed, rays, z, NR, K, tiles, rgbsigma, (unsigned long long *)nullptr);
     return check_launch("points_mlp_f16_kernel");
 }
 

@@ -84,6 +84,11 @@ class NeRFRendererDGS(torch.nn.Module):
         self._calls = 0
         self._maps_key = self._maps_pack = None      # packed depth/sigma/normal maps + cameras
         self._latent_key = self._latent_pack = None  # packed NHWC latent
+        self._linz_key = self._linz_pack = None      # lin_z[b](latent) feature maps (f16x3 mode)
+        # f16x3 mode: hoist lin_z from per point to per latent texel (linear map and bilinear interpolation
+        # commute; diner_pack_linz_maps).  Costs 3x the latent's memory per encode(); set False to keep
+        # lin_z as per-point GEMMs.
+        self.linz_maps = True
         self._mlp_key = None
         self._mlp_pack = None
 
@@ -106,7 +111,7 @@ class NeRFRendererDGS(torch.nn.Module):
             if pe.num_freqs != 6 or not pe.include_input:
                 raise NotImplementedError("positional encoding must be num_freqs=6, include_input=True")
 
-    def _scene(self, model, need_latent=True) -> Tuple[DinerScene, tuple]:
+    def _scene(self, model, need_latent=True, packed_mlp=None) -> Tuple[DinerScene, tuple]:
         enc = model.encoder
         dev = enc.depths.device
         mkey = tuple(_sig(t) for t in (model.poses, model.focal, model.c, model.image_shape, enc.depths,
@@ -138,6 +143,16 @@ class NeRFRendererDGS(torch.nn.Module):
                 self._latent_pack, self._latent_key = latent, lkey
         maps, poses, focal, c, ishape = self._maps_pack
         latent = self._latent_pack if need_latent else None
+        linz = None
+        if need_latent and packed_mlp is not None and self.linz_maps and self.precision == "f16x3":
+            zkey = (self._latent_key, self._mlp_key)
+            if zkey != self._linz_key:
+                SB, NV, h, w, Cc = latent.shape
+                out = torch.empty((3, SB, NV, h, w, Cc), dtype=torch.float32, device=dev)
+                check(_lib.lib().diner_pack_linz_maps(_ptr(latent), SB * NV, h, w, _ptr(packed_mlp), _ptr(out), _stream(dev)),
+                      "diner_pack_linz_maps")
+                self._linz_pack, self._linz_key = out, zkey
+            linz = self._linz_pack
         SB, NV, H, W, _ = maps.shape
         sc = DinerScene()
         sc.SB, sc.NV, sc.H, sc.W = SB, NV, H, W
@@ -151,7 +166,8 @@ class NeRFRendererDGS(torch.nn.Module):
         sc.poses, sc.focal, sc.c = poses.data_ptr(), focal.data_ptr(), c.data_ptr()
         sc.maps = maps.data_ptr()
         sc.latent = latent.data_ptr() if latent is not None else None
-        return sc, (maps, poses, focal, c, latent)
+        sc.linz_maps = linz.data_ptr() if linz is not None else None
+        return sc, (maps, poses, focal, c, latent, linz)
 
     def _mlp(self, model) -> torch.Tensor:
         mlp = model.mlp_fine
@@ -265,9 +281,9 @@ class NeRFRendererDGS(torch.nn.Module):
         r = self._check_rays(rays)
         z = _f32c(z_samp)
         SB, NR, K = z.shape
-        sc, _keep = self._scene(model, need_latent=True)
-        assert SB == sc.SB  # pixelnerf.py:68
         packed = self._mlp(model)
+        sc, _keep = self._scene(model, need_latent=True, packed_mlp=packed)
+        assert SB == sc.SB  # pixelnerf.py:68
         out = torch.empty((SB, NR, K, 4), dtype=torch.float32, device=r.device)
         prec = _lib.PRECISIONS[self.precision]
         check(_lib.lib().diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, prec,
@@ -323,9 +339,9 @@ class NeRFRendererDGS(torch.nn.Module):
                 w_, rgb, depth = self.composite(model, r, z_samples)
                 weights = w_ if want_weights else None
             else:
-                sc, _keep = self._scene(model, need_latent=True)
-                assert SB == sc.SB
                 packed = self._mlp(model)
+                sc, _keep = self._scene(model, need_latent=True, packed_mlp=packed)
+                assert SB == sc.SB
                 cfg = self._cfg(K, self.n_depth_candidates, self.n_gaussian)
                 u_c = n_g = u_f = None
                 if noise is not None:

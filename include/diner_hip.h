@@ -62,6 +62,8 @@ typedef struct DinerScene {
     const float *c;          /* [SB,NV,2] */
     const float *maps;       /* [SB,NV,H,W,8] packed by diner_pack_maps */
     const float *latent;     /* [SB,NV,h,w,C] packed by diner_pack_latent (may be NULL for the sampler) */
+    const float *linz_maps;  /* [3][SB,NV,h,w,C] from diner_pack_linz_maps, or NULL: the F16X3 kernel then
+                                evaluates lin_z per point like the FP32 kernel does */
 } DinerScene;
 
 /* ResnetFC parameters in the reference's nn.Linear layout, weight [out,in]
@@ -96,6 +98,12 @@ int diner_pack_latent(const float *latent_nchw, int64_t N, int32_t C, int32_t h,
  * precision mode, both in the same buffer) ------------------------------------------------ */
 int64_t diner_mlp_packed_floats(void);
 int diner_pack_mlp(const DinerMlpRaw *raw, float *packed_out, void *stream);
+/* ---- once per (encode, weight version): G_b = lin_z[b](latent), b = 0..2, as feature maps ----
+ * lin_z (src/models/resnetfc.py:152) is linear and SpatialEncoder.index (src/models/image_encoder.py:97-127)
+ * is a 4-texel convex combination, so lin_z[b](index(uv)) == bilerp(G_b)(uv) up to fp32 rounding.
+ * latent_packed [N,h,w,512] from diner_pack_latent, mlp_packed from diner_pack_mlp -> out [3][N,h,w,512]. */
+int diner_pack_linz_maps(const float *latent_packed, int64_t N, int32_t h, int32_t w, const float *mlp_packed,
+                         float *out, void *stream);
 
 /* ---- the hot path ---------------------------------------------------------------------- */
 /* Stage entry points with the reference's stage boundaries (for stage-level parity tests and for

@@ -32,13 +32,14 @@ def model_for(g, dev):
     return _models[g.name]
 
 
-PRECISIONS = ["fp32", "f16x3"]
+PRECISIONS = ["fp32", "f16x3", "f16x3-gemm"]  # f16x3 = lin_z hoisted to feature maps; -gemm = per-point lin_z GEMMs
 
 
 def renderer_for(g, precision="f16x3"):
     from diner_amd import NeRFRendererDGS
     r = NeRFRendererDGS(n_samples=g.K, n_depth_candidates=g.NC, n_gaussian=g.G, white_bkgd=g.scene.white_bkgd)
-    r.precision = precision
+    r.precision = precision.split("-")[0]
+    r.linz_maps = not precision.endswith("-gemm")
     return r
 
 

@@ -49,6 +49,23 @@ __global__ __launch_bounds__(256) void rate_kernel(const _Float16 *src, float *o
     out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+typedef float f4v __attribute__((ext_vector_type(4)));
+template <int NACC>
+__global__ __launch_bounds__(256) void rate16_kernel(const _Float16 *src, float *out, int iters)
+{
+    h8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = src[(threadIdx.x * 8 + j) & 4095]; b[j] = src[(threadIdx.x * 8 + j + 777) & 4095]; }
+    f4v c[NACC];
+    for (int n = 0; n < NACC; ++n) for (int i = 0; i < 4; ++i) c[n][i] = 0.f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) c[n] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c[n], 0, 0, 0);
+    }
+    float s = 0.f;
+    for (int n = 0; n < NACC; ++n) for (int i = 0; i < 4; ++i) s += c[n][i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
 int main()
 {
     float *d; hipMalloc(&d, 1 << 22);
@@ -88,6 +105,22 @@ int main()
         float ms; hipEventElapsedTime(&ms, e0, e1);
         const double flop = (double)blocks * 4 * iters * 4 * 32768.0;
         printf("f16 32x32x16 rate: %.1f TFLOP/s (%.2f ms)\n", flop / ms / 1e9, ms);
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        rate16_kernel<8><<<blocks, 256>>>(src, d, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double flop = (double)blocks * 4 * iters * 8 * 16384.0;
+        printf("f16 16x16x32 rate: %.1f TFLOP/s (%.2f ms)\n", flop / ms / 1e9, ms);
+    }
+    for (int rep = 0; rep < 3; ++rep) {
+        hipEventRecord(e0);
+        rate_kernel<4><<<blocks, 256>>>(src, d, iters);
+        hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double flop = (double)blocks * 4 * iters * 4 * 32768.0;
+        printf("f16 32x32x16 rate (again): %.1f TFLOP/s (%.2f ms)\n", flop / ms / 1e9, ms);
     }
     return 0;
 }
