@@ -55,9 +55,10 @@ SYMBOLS = {
     "diner_sample_depthguided": (C.c_int, [C.POINTER(DinerScene), _P, _I64, C.POINTER(DinerSamplerCfg),
                                            _P, _P, _P, _P, _U64, _P, _P, _P, _P]),
     "diner_fill_up_uniform_samples": (C.c_int, [_P, _P, _I64, _I32, _P, _U64, _P, _P]),
-    "diner_render_points": (C.c_int, [C.POINTER(DinerScene), _P, _P, _P, _I64, _I32, _I32, _P, _P]),
+    "diner_render_points_scratch_floats": (_I64, [_I64, _I32, _I32]),
+    "diner_render_points": (C.c_int, [C.POINTER(DinerScene), _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
     "diner_composite": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
-    "diner_render_workspace_floats": (_I64, [_I64, _I64, _I32]),
+    "diner_render_workspace_floats": (_I64, [_I64, _I64, _I32, _I32, _I32]),
     "diner_render": (C.c_int, [C.POINTER(DinerScene), _P, _P, _I64, C.POINTER(DinerSamplerCfg), _I32, _I32,
                                _P, _P, _P, _U64, _P, _P, _P, _P, _P]),
 }

@@ -40,7 +40,8 @@ int launch_fill_up(const float *, const float *, int64_t, int, const float *, ui
 int launch_points_mlp(const DinerScene &, const float *, const float *, const float *, int64_t, int, float *, hipStream_t);
 int64_t mlp_f16_packed_floats();
 int launch_pack_mlp_f16(const DinerMlpRaw &, float *, hipStream_t);
-int launch_points_mlp_f16(const DinerScene &, const float *, const float *, const float *, int64_t, int, float *, hipStream_t);
+int launch_points_mlp_f16(const DinerScene &, const float *, const float *, const float *, int64_t, int, float *, float *, hipStream_t);
+int64_t points_mlp_f16_scratch_floats(int64_t SB, int NV);
 
 static int bad(const char *msg)
 {
@@ -144,8 +145,13 @@ int diner_sample_depthguided(const DinerScene *scene, const float *rays, int64_t
                           (hipStream_t)stream);
 }
 
+int64_t diner_render_points_scratch_floats(int64_t SB, int32_t NV, int32_t precision)
+{
+    return precision == DINER_PRECISION_F16X3 ? points_mlp_f16_scratch_floats(SB, NV) : 0;
+}
+
 int diner_render_points(const DinerScene *scene, const float *mlp_packed, const float *rays, const float *z,
-                        int64_t NR, int32_t K, int32_t precision, float *rgbsigma_out, void *stream)
+                        int64_t NR, int32_t K, int32_t precision, float *scratch, float *rgbsigma_out, void *stream)
 {
     int rc;
     if ((rc = check_scene(scene, true))) return rc;
@@ -154,7 +160,8 @@ int diner_render_points(const DinerScene *scene, const float *mlp_packed, const 
     if (NR > 0 && scene->SB > 0 && (!rays || !z || !rgbsigma_out)) return bad("render_points: NULL rays / z / out");
     if (precision == DINER_PRECISION_FP32) return launch_points_mlp(*scene, mlp_packed, rays, z, NR, K, rgbsigma_out, (hipStream_t)stream);
     if (precision == DINER_PRECISION_F16X3)
-        return launch_points_mlp_f16(*scene, mlp_packed + mlp_packed_floats(), rays, z, NR, K, rgbsigma_out, (hipStream_t)stream);
+        return launch_points_mlp_f16(*scene, mlp_packed + mlp_packed_floats(), rays, z, NR, K, scratch, rgbsigma_out,
+                                     (hipStream_t)stream);
     return bad("render_points: unknown precision");
 }
 
@@ -166,7 +173,10 @@ int diner_composite(const float *rays, const float *z, const float *rgbsigma, in
     return launch_composite(rays, z, rgbsigma, N, K, white_bkgd, rgb_out, depth_out, weights_out, (hipStream_t)stream);
 }
 
-int64_t diner_render_workspace_floats(int64_t SB, int64_t NR, int32_t K) { return SB * NR * (int64_t)K * 5; }
+int64_t diner_render_workspace_floats(int64_t SB, int64_t NR, int32_t K, int32_t NV, int32_t precision)
+{
+    return SB * NR * (int64_t)K * 5 + diner_render_points_scratch_floats(SB, NV, precision);
+}
 
 int diner_render(const DinerScene *scene, const float *mlp_packed, const float *rays, int64_t NR,
                  const DinerSamplerCfg *cfg, int32_t white_bkgd, int32_t precision, const float *u_coarse, const float *n_gauss,
@@ -179,11 +189,11 @@ int diner_render(const DinerScene *scene, const float *mlp_packed, const float *
     if (NR == 0 || scene->SB == 0) return DINER_OK;
     if (!workspace) return bad("render: workspace is NULL");
     const int64_t N = (int64_t)scene->SB * NR;
-    float *z = workspace, *rgbsigma = workspace + N * cfg->n_samples;
+    float *z = workspace, *rgbsigma = workspace + N * cfg->n_samples, *scratch = workspace + N * cfg->n_samples * 5;
     if ((rc = diner_sample_depthguided(scene, rays, NR, cfg, u_coarse, n_gauss, u_fill, nullptr, seed, z, nullptr,
                                        nullptr, stream)))
         return rc;
-    if ((rc = diner_render_points(scene, mlp_packed, rays, z, NR, cfg->n_samples, precision, rgbsigma, stream))) return rc;
+    if ((rc = diner_render_points(scene, mlp_packed, rays, z, NR, cfg->n_samples, precision, scratch, rgbsigma, stream))) return rc;
     return diner_composite(rays, z, rgbsigma, N, cfg->n_samples, white_bkgd, rgb_out, depth_out, weights_out, stream);
 }
 

@@ -29,7 +29,10 @@
 //   * weights stream through a 2-deep register ring written with inline-asm loads and counted waits
 //     (hipcc sinks ordinary prefetch loads to their first use); measured with in-kernel stamps the GEMM
 //     phases already run at the chip's sustained fp16-MFMA rate on random data (~1.5 PFLOP/s, clock-
-//     limited), so a deeper ring buys nothing and the registers go to the view-sum instead;
+//     limited), so a deeper ring buys nothing;
+//   * the per-view hidden states wait for the mean over views in a per-workgroup global scratch
+//     (write-only until the last view), not in 64 more registers: with 192 accumulator registers the
+//     compiler spilled inside the activation-store and gather code;
 //   * persistent workgroups (one per CU): all biases are staged in LDS once, and in each round the
 //     workgroups of one XCD take a contiguous run of tiles, so neighbouring texels share one L2.
 #include <stdio.h>
@@ -228,6 +231,8 @@ __device__ __forceinline__ void store_relu(const f32x16 (&acc)[CT][2], _Float16 
         }
 }
 
+constexpr int SLAB_FLOATS = TILE_P * HID;  // one view's x of one tile (128 KiB)
+
 struct Tap {
     int o00, o01, o10, o11;  // float4 offsets of the 4 texels (clamped, always readable)
     float nw, ne, sw, se;    // weights; a tap outside the map has its weight forced to 0
@@ -242,7 +247,7 @@ template <bool STAMP, bool LINZ>
 __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene s, const float *__restrict__ Wp,
                                                                      const float *__restrict__ rays,
                                                                      const float *__restrict__ zsamp, int64_t NR, int K,
-                                                                     int64_t tiles,
+                                                                     int64_t tiles, float *__restrict__ scratch,
                                                                      float *__restrict__ rgbsigma,
                                                                      unsigned long long *__restrict__ dbg)
 {
@@ -275,6 +280,8 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
     const int64_t P = NR * (int64_t)K;
     const _Float16 *Wh = (const _Float16 *)Wp;
     for (int i = threadIdx.x; i < BIAS_FLOATS; i += NWAVES * 64) bias[i] = (Wp + W_HALFS / 2)[i];
+    // this lane's slice of the workgroup's scratch: [view][wave][tn][tp][i][lane] (coalesced 256-B rows)
+    float *xs = scratch + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (int64_t)(s.NV - 1) * SLAB_FLOATS + wave * (CT * 2 * 16 * 64) + lane;
     const float sxl = ((float)s.w - s.feature_padding * 2.0f) / (float)s.w;  // image_encoder.py:113-114
     const float syl = ((float)s.h - s.feature_padding * 2.0f) / (float)s.h;
     const int row = tid & 63;
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
         const float dwx = rp[3], dwy = rp[4], dwz = rp[5];
         const float wx = rp[0] + zz * dwx, wy = rp[1] + zz * dwy, wz = rp[2] + zz * dwz;  // nerf_renderer.py:304
 
-        f32x16 x[CT][2], net[CT][2], xsum[CT][2];
+        f32x16 x[CT][2], net[CT][2];
         for (int v = 0; v < s.NV; ++v) {
             // ---- geometry + positional encodings -> images[:, 0:64] (55 real inputs); footprint -> taps ----
             {
@@ -431,21 +438,37 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
                 gemm_tile<NKB_FULL>(x, Ahi8, Alo8, (const h8 *)(Wh + OFF_FC1 + b * W_FULL), wave, lane);
                 cur_phase = PH_GEMM; BARRIER()
             }
-            // ---- running sum over views (resnetfc.py:146-149) ----------------------------------------
+            // ---- mean over views (resnetfc.py:146-149, combine()): views 0..NV-2 park their x in this
+            //      workgroup's scratch slabs (fire-and-forget stores, nothing waits on them); the last view
+            //      sums the slabs in the reference's order ((x0 + x1) + x2) + ... and divides
+            if (s.NV > 1) {
+                if (v < s.NV - 1) {
 #pragma unroll
-            for (int tn = 0; tn < CT; ++tn)
+                    for (int tn = 0; tn < CT; ++tn)
 #pragma unroll
-                for (int tp = 0; tp < 2; ++tp) xsum[tn][tp] = (v == 0) ? x[tn][tp] : xsum[tn][tp] + x[tn][tp];
+                        for (int tp = 0; tp < 2; ++tp)
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) xs[(int64_t)v * SLAB_FLOATS + ((tn * 2 + tp) * 16 + i) * 64] = x[tn][tp][i];
+                } else {
+                    const float nv = (float)s.NV;
+#pragma unroll
+                    for (int tn = 0; tn < CT; ++tn)
+#pragma unroll
+                        for (int tp = 0; tp < 2; ++tp) {
+                            f32x16 sum;
+#pragma unroll
+                            for (int i = 0; i < 16; ++i) sum[i] = xs[((tn * 2 + tp) * 16 + i) * 64];
+                            for (int u = 1; u < s.NV - 1; ++u) {
+                                f32x16 t;
+#pragma unroll
+                                for (int i = 0; i < 16; ++i) t[i] = xs[(int64_t)u * SLAB_FLOATS + ((tn * 2 + tp) * 16 + i) * 64];
+                                sum += t;
+                            }
+                            x[tn][tp] = (sum + x[tn][tp]) / nv;
+                        }
+                }
+            }
             PHASE(PH_VIEWSUM)
-        }
-        {
-            const float nv = (float)s.NV;
-#pragma unroll
-            for (int tn = 0; tn < CT; ++tn)
-#pragma unroll
-                for (int tp = 0; tp < 2; ++tp)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) x[tn][tp][i] = xsum[tn][tp][i] / nv;  // combine(): mean over views
         }
         for (int b = DINER_COMBINE_LAYER; b < DINER_N_BLOCKS; ++b) {
             store_relu(x, Ahi, Alo, wave, lane);
@@ -520,14 +543,20 @@ static int f16_grid_limit()
     return cus;
 }
 
+int64_t points_mlp_f16_scratch_floats(int64_t SB, int NV)
+{
+    return NV > 1 ? (int64_t)f16_grid_limit() * SB * (NV - 1) * f16x3::SLAB_FLOATS : 0;
+}
+
 int launch_points_mlp_f16(const DinerScene &s, const float *mlp_packed, const float *rays, const float *z, int64_t NR,
-                          int K, float *rgbsigma, hipStream_t st)
+                          int K, float *scratch, float *rgbsigma, hipStream_t st)
 {
     using namespace f16x3;
     const int64_t P = NR * (int64_t)K;
     if (P == 0 || s.SB == 0) return DINER_OK;
     if (s.C != DINER_D_LATENT) { set_error("render_points: latent channels C=%d unsupported (need %d)", s.C, DINER_D_LATENT); return DINER_E_UNSUPPORTED; }
     if (s.num_freqs != 6) { set_error("render_points: num_freqs=%d unsupported (need 6)", s.num_freqs); return DINER_E_UNSUPPORTED; }
+    if (!scratch && s.NV > 1) { set_error("render_points(f16x3): scratch is NULL"); return DINER_E_INVALID; }
     const int64_t tiles = (P + TILE_P - 1) / TILE_P;
     const int64_t grid = tiles < f16_grid_limit() ? tiles : f16_grid_limit();
     static const bool stamp = getenv("DINER_F16_STAMP") != nullptr;  // diagnostics only
@@ -536,7 +565,7 @@ int launch_points_mlp_f16(const DinerScene &s, const float *mlp_packed, const fl
         if (!dbg && hipMalloc(&dbg, NWAVES * PH_COUNT * sizeof(unsigned long long)) != hipSuccess) return DINER_E_LAUNCH;
         (void)hipMemsetAsync(dbg, 0, NWAVES * PH_COUNT * sizeof(unsigned long long), st);
         hipLaunchKernelGGL((points_mlp_f16_kernel<true, true>), dim3((unsigned)grid, (unsigned)s.SB), dim3(NWAVES * 64), 0, st, s,
-                           mlp_packed, rays, z, NR, K, tiles, rgbsigma, dbg);
+                           mlp_packed, rays, z, NR, K, tiles, scratch, rgbsigma, dbg);
         unsigned long long h[NWAVES * PH_COUNT];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost);
@@ -552,10 +581,10 @@ int launch_points_mlp_f16(const DinerScene &s, const float *mlp_packed, const fl
     }
     if (s.linz_maps)
         hipLaunchKernelGGL((points_mlp_f16_kernel<false, true>), dim3((unsigned)grid, (unsigned)s.SB), dim3(NWAVES * 64), 0, st, s,
-                           mlp_packed, rays, z, NR, K, tiles, rgbsigma, (unsigned long long *)nullptr);
+                           mlp_packed, rays, z, NR, K, tiles, scratch, rgbsigma, (unsigned long long *)nullptr);
     else
         hipLaunchKernelGGL((points_mlp_f16_kernel<false, false>), dim3((unsigned)grid, (unsigned)s.SB), dim3(NWAVES * 64), 0, st, s,
-                           mlp_packed, rays, z, NR, K, tiles, rgbsigma, (unsigned long long *)nullptr);
+                           mlp_packed, rays, z, NR, K, tiles, scratch, rgbsigma, (unsigned long long *)nullptr);
     return check_launch("points_mlp_f16_kernel");
 }
 

@@ -286,7 +286,9 @@ class NeRFRendererDGS(torch.nn.Module):
         assert SB == sc.SB  # pixelnerf.py:68
         out = torch.empty((SB, NR, K, 4), dtype=torch.float32, device=r.device)
         prec = _lib.PRECISIONS[self.precision]
-        check(_lib.lib().diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, prec,
+        n_scr = int(_lib.lib().diner_render_points_scratch_floats(SB, sc.NV, prec))
+        scr = torch.empty(n_scr, dtype=torch.float32, device=r.device) if n_scr else None
+        check(_lib.lib().diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, prec, _ptr(scr),
                                              _ptr(out), _stream(r.device)),
               "diner_render_points")
         return out
@@ -347,7 +349,7 @@ class NeRFRendererDGS(torch.nn.Module):
                 if noise is not None:
                     u_c, n_g, u_f = [None if t is None else _f32c(t).to(dev) for t in noise]
                 prec = _lib.PRECISIONS[self.precision]
-                ws = torch.empty(int(_lib.lib().diner_render_workspace_floats(SB, NR, K)), dtype=torch.float32, device=dev)
+                ws = torch.empty(int(_lib.lib().diner_render_workspace_floats(SB, NR, K, sc.NV, prec)), dtype=torch.float32, device=dev)
                 L, st, seed = _lib.lib(), _stream(dev), self._next_seed()
                 if self.stage_events is None:
                     check(L.diner_render(C.byref(sc), _ptr(packed), _ptr(r), NR, C.byref(cfg), int(bool(self.white_bkgd)),
@@ -355,13 +357,13 @@ class NeRFRendererDGS(torch.nn.Module):
                                          _ptr(weights), st), "diner_render")
                 else:
                     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
-                    z, c = ws[:SB * NR * K], ws[SB * NR * K:]
+                    z, c, scr = ws[:SB * NR * K], ws[SB * NR * K:SB * NR * K * 5], ws[SB * NR * K * 5:]
                     ev[0].record()
                     check(L.diner_sample_depthguided(C.byref(sc), _ptr(r), NR, C.byref(cfg), _ptr(u_c), _ptr(n_g), _ptr(u_f),
                                                      None, seed, _ptr(z), None, None, st), "diner_sample_depthguided")
                     ev[1].record()
                     check(L.diner_render_points(C.byref(sc), _ptr(packed), _ptr(r), _ptr(z), NR, K, prec,
-                                                _ptr(c), st),
+                                                _ptr(scr) if scr.numel() else None, _ptr(c), st),
                           "diner_render_points")
                     ev[2].record()
                     check(L.diner_composite(_ptr(r), _ptr(z), _ptr(c), SB * NR, K, int(bool(self.white_bkgd)), _ptr(rgb),

@@ -137,10 +137,13 @@ int diner_sample_depthguided(const DinerScene *scene, const float *rays, int64_t
 /* Replaces the model evaluation inside composite(): points = o + z*d (:304-307) and
  * PixelNeRF.forward (src/models/pixelnerf.py:55-145) incl. PositionalEncoding.forward,
  * SpatialEncoder.index / index_depth and ResnetFC.forward.  z [SB,NR,K] -> rgbsigma [SB,NR,K,4].
- * mlp_packed from diner_pack_mlp. */
+ * mlp_packed from diner_pack_mlp.  scratch: device buffer of diner_render_points_scratch_floats()
+ * floats (the F16X3 kernel parks per-view hidden states there until the mean over views; may be
+ * NULL when that is 0); one buffer per concurrently running launch. */
+int64_t diner_render_points_scratch_floats(int64_t SB, int32_t NV, int32_t precision);
 int diner_render_points(const DinerScene *scene, const float *mlp_packed, const float *rays,
-                        const float *z, int64_t NR, int32_t K, int32_t precision, float *rgbsigma_out,
-                        void *stream);
+                        const float *z, int64_t NR, int32_t K, int32_t precision, float *scratch,
+                        float *rgbsigma_out, void *stream);
 
 /* Replaces the alpha compositing of composite() (src/models/nerf_renderer.py:299-301,341-360).
  * N rays (= SB*NR).  weights_out [N,K] optional. */
@@ -150,8 +153,8 @@ int diner_composite(const float *rays, const float *z, const float *rgbsigma, in
 
 /* Replaces NeRFRendererDGS.forward (src/models/nerf_renderer.py:399-424): the three stages
  * back to back on `stream`.  workspace: device buffer of diner_render_workspace_floats(...)
- * floats (holds z and rgbsigma). */
-int64_t diner_render_workspace_floats(int64_t SB, int64_t NR, int32_t K);
+ * floats (holds z, rgbsigma and the point kernel's scratch). */
+int64_t diner_render_workspace_floats(int64_t SB, int64_t NR, int32_t K, int32_t NV, int32_t precision);
 int diner_render(const DinerScene *scene, const float *mlp_packed, const float *rays, int64_t NR,
                  const DinerSamplerCfg *cfg, int32_t white_bkgd, int32_t precision, const float *u_coarse,
                  const float *n_gauss, const float *u_fill, uint64_t seed, float *workspace,
