@@ -232,6 +232,7 @@ __device__ __forceinline__ void store_relu(const f32x16 (&acc)[CT][2], _Float16 
 }
 
 constexpr int SLAB_FLOATS = TILE_P * HID;  // one view's x of one tile (128 KiB)
+constexpr int SYNC_WORDS = 256;            // head of the scratch: 8 pacing counters, one per 128-byte line
 
 struct Tap {
     int o00, o01, o10, o11;  // float4 offsets of the 4 texels (clamped, always readable)
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
     const _Float16 *Wh = (const _Float16 *)Wp;
     for (int i = threadIdx.x; i < BIAS_FLOATS; i += NWAVES * 64) bias[i] = (Wp + W_HALFS / 2)[i];
     // this lane's slice of the workgroup's scratch: [view][wave][tn][tp][i][lane] (coalesced 256-B rows)
-    float *xs = scratch + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (int64_t)(s.NV - 1) * SLAB_FLOATS + wave * (CT * 2 * 16 * 64) + lane;
+    float *xs = scratch + SYNC_WORDS + ((int64_t)blockIdx.y * gridDim.x + blockIdx.x) * (int64_t)(s.NV - 1) * SLAB_FLOATS + wave * (CT * 2 * 16 * 64) + lane;
     const float sxl = ((float)s.w - s.feature_padding * 2.0f) / (float)s.w;  // image_encoder.py:113-114
     const float syl = ((float)s.h - s.feature_padding * 2.0f) / (float)s.h;
     const int row = tid & 63;
@@ -294,7 +295,27 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
         const int64_t nwg = gridDim.x, b = blockIdx.x, q = nwg / 8, r = nwg % 8, xcd = b % 8;
         slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
     }
-    for (int64_t tile = slot; tile < tiles; tile += gridDim.x) {
+    // Pacing (speed only, no data is exchanged): the workgroups that share an XCD (equal blockIdx % 8) start
+    // every tile together.  They all stream the same 1 MiB weight layers in the same order; kept in step, one
+    // fetch from the Infinity Cache serves the whole XCD through its L2, while drifting apart they each
+    // miss (measured: L2 hit rate 56 % unpaced).  A monotonic counter per group, bounded polling: a
+    // workgroup that times out simply goes on, so residency or placement can never turn this into a hang.
+    unsigned int *pace = (unsigned int *)scratch + (blockIdx.x & 7) * 32;
+    const unsigned int group = (gridDim.x + 7 - (blockIdx.x & 7)) / 8 * gridDim.y;  // workgroups with this residue
+    const int64_t full_rounds = tiles / gridDim.x;                                   // rounds in which every workgroup has a tile
+    int64_t round = 0;
+    for (int64_t tile = slot; tile < tiles; tile += gridDim.x, ++round) {
+        if (round < full_rounds && group > 1) {
+            if (tid == 0) {
+                __hip_atomic_fetch_add(pace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned int want = (unsigned int)(round + 1) * group;
+                for (int spin = 0; spin < 20000; ++spin) {
+                    if (__hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
+                    __builtin_amdgcn_s_sleep(8);
+                }
+            }
+            __syncthreads();
+        }
         int64_t p = tile * TILE_P + row;
         if (p > P - 1) p = P - 1;  // tail tile: duplicate the last point, masked at the store
         const int64_t ray = p / K;
@@ -545,7 +566,7 @@ static int f16_grid_limit()
 
 int64_t points_mlp_f16_scratch_floats(int64_t SB, int NV)
 {
-    return NV > 1 ? (int64_t)f16_grid_limit() * SB * (NV - 1) * f16x3::SLAB_FLOATS : 0;
+    return f16x3::SYNC_WORDS + (NV > 1 ? (int64_t)f16_grid_limit() * SB * (NV - 1) * f16x3::SLAB_FLOATS : 0);
 }
 
 int launch_points_mlp_f16(const DinerScene &s, const float *mlp_packed, const float *rays, const float *z, int64_t NR,
@@ -556,7 +577,8 @@ int launch_points_mlp_f16(const DinerScene &s, const float *mlp_packed, const fl
     if (P == 0 || s.SB == 0) return DINER_OK;
     if (s.C != DINER_D_LATENT) { set_error("render_points: latent channels C=%d unsupported (need %d)", s.C, DINER_D_LATENT); return DINER_E_UNSUPPORTED; }
     if (s.num_freqs != 6) { set_error("render_points: num_freqs=%d unsupported (need 6)", s.num_freqs); return DINER_E_UNSUPPORTED; }
-    if (!scratch && s.NV > 1) { set_error("render_points(f16x3): scratch is NULL"); return DINER_E_INVALID; }
+    if (!scratch) { set_error("render_points(f16x3): scratch is NULL"); return DINER_E_INVALID; }
+    if (hipMemsetAsync(scratch, 0, SYNC_WORDS * sizeof(float), st) != hipSuccess) return check_launch("memset(pacing counters)");
     const int64_t tiles = (P + TILE_P - 1) / TILE_P;
     const int64_t grid = tiles < f16_grid_limit() ? tiles : f16_grid_limit();
     static const bool stamp = getenv("DINER_F16_STAMP") != nullptr;  // diagnostics only
