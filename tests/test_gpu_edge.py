@@ -1,0 +1,191 @@
+"""GPU edge cases of the render path, checked against the CPU oracle on the same seeded inputs
+(no golden needed: the oracle is pinned by tests/test_oracle_golden.py): batches of scenes, 1 and
+8 source views, every candidate-count kernel variant, K = 256, ragged tails, empty inputs,
+n_gaussian = 0 / = K, rays that miss everything, chunk invariance.  All through the plug-in class
+and therefore the C ABI."""
+import copy
+
+import numpy as np
+import pytest
+import torch
+
+from diner_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda:0")
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def make(H=24, W=24, NV=3, seed=0, **kw):
+    sc = synth.make_scene(H, W, NV, seed=seed, feature_padding=4, **kw)
+    w = synth.make_mlp_weights(seed + 1, bias_scale=0.1)
+    return sc, w
+
+
+def run_gpu(sc, w, rays, K, NC, G, noise, dev, precision="f16x3", want_weights=True):
+    from diner_amd import NeRFRendererDGS
+    from diner_amd.model_stub import model_from_scene
+    m = model_from_scene(sc, w, device=dev)
+    r = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G, white_bkgd=sc.white_bkgd)
+    r.precision = precision
+    with torch.no_grad():
+        out = r(m, T(rays, dev), want_weights=want_weights, noise=None if noise is None else tuple(None if n is None else T(n, dev) for n in noise))
+    return out, r, m
+
+
+def run_oracle(sc, w, rays, K, NC, G, noise):
+    from oracle.oracle import Oracle
+    return Oracle(sc, w).render(rays, NC, K, G, noise, white_bkgd=sc.white_bkgd)
+
+
+def agree(out_rgb, ref_rgb, frac=0.97, tol=1e-4):
+    ok = np.abs(out_rgb - ref_rgb).max(-1) <= tol
+    assert ok.mean() >= frac, f"{(~ok).sum()} of {ok.size} rays differ by more than {tol}"
+
+
+@pytest.mark.parametrize("NV", [1, 2, 8])
+def test_number_of_views(dev, NV):
+    sc, w = make(NV=NV, seed=20 + NV)
+    rays = sc.target_rays()[:, ::5]
+    K, NC, G = 24, 300, 8
+    noise = synth.make_noise(rays.shape[1], NC, G, K, seed=1)
+    out, _, _ = run_gpu(sc, w, rays, K, NC, G, noise, dev)
+    ref = run_oracle(sc, w, rays, K, NC, G, noise)
+    agree(out.fine.rgb.cpu().numpy()[0], ref["rgb"])
+
+
+@pytest.mark.parametrize("NC,K,G", [(64, 8, 2), (250, 16, 4), (1000, 256, 96), (1500, 40, 15), (2048, 32, 8)])
+def test_candidate_and_sample_counts(dev, NC, K, G):
+    """NC selects the sampler's candidates-per-lane variant (4 / 16 / 32); K = 256 is cfg5's sample count."""
+    sc, w = make(seed=30)
+    rays = sc.target_rays()[:, ::9]
+    noise = synth.make_noise(rays.shape[1], NC, G, K, seed=2)
+    out, _, _ = run_gpu(sc, w, rays, K, NC, G, noise, dev)
+    ref = run_oracle(sc, w, rays, K, NC, G, noise)
+    z = out.fine.weights  # shape check only
+    assert tuple(z.shape) == (1, rays.shape[1], K)
+    agree(out.fine.rgb.cpu().numpy()[0], ref["rgb"], frac=0.95)
+
+
+def test_unsupported_candidate_count_raises(dev):
+    sc, w = make(seed=31)
+    rays = sc.target_rays()[:, :4]
+    with pytest.raises(NotImplementedError):
+        run_gpu(sc, w, rays, 8, 4096, 2, None, dev)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_batch_of_two_scenes(dev, precision):
+    """SB = 2 (the reference trains with batches of scenes, pixelnerf.py:68): every scene of the batch must
+    equal its own single-scene render."""
+    a, w = make(seed=40)
+    b, _ = make(seed=41, bg_sigma_zero=True)
+    both = copy.copy(a)
+    for name in ("poses", "focal", "c", "depths", "depths_std", "normals", "latent"):
+        setattr(both, name, np.concatenate([getattr(a, name), getattr(b, name)], 0))
+    ra, rb = a.target_rays()[:, ::7], b.target_rays()[:, 3::7]
+    n = min(ra.shape[1], rb.shape[1])
+    rays = np.concatenate([ra[:, :n], rb[:, :n]], 0)
+    K, NC, G = 16, 200, 5
+    na, nb = synth.make_noise(n, NC, G, K, seed=3), synth.make_noise(n, NC, G, K, seed=4)
+    noise = tuple(np.stack([x, y]) for x, y in zip(na, nb))
+    out, _, _ = run_gpu(both, w, rays, K, NC, G, noise, dev, precision=precision)
+    rgb = out.fine.rgb.cpu().numpy()
+    assert rgb.shape == (2, n, 3)
+    agree(rgb[0], run_oracle(a, w, ra[:, :n], K, NC, G, na)["rgb"])
+    agree(rgb[1], run_oracle(b, w, rb[:, :n], K, NC, G, nb)["rgb"])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "f16x3"])
+def test_ragged_tail_and_tiny_inputs(dev, precision):
+    """Point counts that are not a multiple of the 64-point tile, down to a single ray."""
+    sc, w = make(seed=50)
+    K, NC, G = 40, 200, 15  # reference defaults for K and G (configs/train_diner_facescape.yaml:61-66)
+    for n_rays in (1, 7, 33):
+        rays = sc.target_rays()[:, 100:100 + n_rays]
+        noise = synth.make_noise(n_rays, NC, G, K, seed=5)
+        out, _, _ = run_gpu(sc, w, rays, K, NC, G, noise, dev, precision=precision)
+        ref = run_oracle(sc, w, rays, K, NC, G, noise)
+        np.testing.assert_allclose(out.fine.rgb.cpu().numpy()[0], ref["rgb"], rtol=0, atol=1e-4)
+        np.testing.assert_allclose(out.fine.depth.cpu().numpy()[0], ref["depth"], rtol=0, atol=2e-4)
+
+
+def test_empty_ray_batch(dev):
+    sc, w = make(seed=51)
+    rays = sc.target_rays()[:, :0]
+    out, _, _ = run_gpu(sc, w, rays, 8, 64, 2, None, dev)
+    assert tuple(out.fine.rgb.shape) == (1, 0, 3) and tuple(out.fine.depth.shape) == (1, 0)
+    assert tuple(out.fine.weights.shape) == (1, 0, 8)
+
+
+@pytest.mark.parametrize("G", [0, 12])
+def test_gaussian_count_extremes(dev, G):
+    """n_gaussian = 0 (no gaussian draws, nerf_renderer.py:181) and n_gaussian = n_samples (nothing short-listed)."""
+    sc, w = make(seed=52)
+    K, NC = 12, 128
+    rays = sc.target_rays()[:, ::11]
+    noise = synth.make_noise(rays.shape[1], NC, max(G, 1), K, seed=6)
+    noise = (noise[0], noise[1][:, :G] if G else np.zeros((rays.shape[1], 0), np.float32), noise[2])
+    out, _, _ = run_gpu(sc, w, rays, K, NC, G, noise if G else (noise[0], None, noise[2]), dev)
+    ref = run_oracle(sc, w, rays, K, NC, G, (noise[0], noise[1] if G else np.zeros((rays.shape[1], 1), np.float32), noise[2]))
+    agree(out.fine.rgb.cpu().numpy()[0], ref["rgb"])
+
+
+def test_rays_that_miss_every_surface(dev):
+    """No candidate has a likelihood: all K samples come from the uniform fill-up (nerf_renderer.py:376-396)."""
+    sc, w = make(seed=53)
+    rays = sc.target_rays()[:, ::13].copy()
+    rays[..., 3:6] = -rays[..., 3:6]  # look away from the object
+    K, NC, G = 16, 100, 4
+    noise = synth.make_noise(rays.shape[1], NC, G, K, seed=7)
+    from diner_amd import NeRFRendererDGS
+    from diner_amd.model_stub import model_from_scene
+    from oracle.oracle import Oracle
+    m = model_from_scene(sc, w, device=dev)
+    r = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G)
+    z = r._sample(T(rays, dev), m, K, NC, G, 0.05, tuple(T(n, dev) for n in noise), None)["z"].cpu().numpy()[0]
+    orc = Oracle(sc, w)
+    zc = orc.sample_coarse(rays, NC, noise[0])
+    zd = orc.sample_depthguided(rays, zc, K, G, noise[1])
+    assert not zd.any(), "scene construction: these rays should have no likelihood"
+    np.testing.assert_array_equal(z, orc.fill_up(rays, zd, noise[2]))
+
+
+def test_chunk_invariance(dev):
+    """Rendering a ray batch in two calls equals one call (sub-batch invariance)."""
+    sc, w = make(seed=54)
+    rays = sc.target_rays()[:, ::3]
+    n = rays.shape[1]
+    K, NC, G = 16, 200, 5
+    noise = synth.make_noise(n, NC, G, K, seed=8)
+    full, _, _ = run_gpu(sc, w, rays, K, NC, G, noise, dev, precision="fp32")
+    h = n // 2 + 3
+    a, _, _ = run_gpu(sc, w, rays[:, :h], K, NC, G, tuple(x[:h] for x in noise), dev, precision="fp32")
+    b, _, _ = run_gpu(sc, w, rays[:, h:], K, NC, G, tuple(x[h:] for x in noise), dev, precision="fp32")
+    np.testing.assert_array_equal(torch.cat([a.fine.rgb, b.fine.rgb], 1).cpu().numpy(), full.fine.rgb.cpu().numpy())
+    np.testing.assert_array_equal(torch.cat([a.fine.depth, b.fine.depth], 1).cpu().numpy(), full.fine.depth.cpu().numpy())
+
+
+def test_cache_invalidation_on_new_encode(dev):
+    """The packed copies are keyed on tensor identity/version: writing new maps in place must be picked up."""
+    sc, w = make(seed=55)
+    rays = sc.target_rays()[:, ::8]
+    K, NC, G = 16, 200, 5
+    noise = synth.make_noise(rays.shape[1], NC, G, K, seed=9)
+    out1, r, m = run_gpu(sc, w, rays, K, NC, G, noise, dev)
+    with torch.no_grad():
+        m.encoder.latent.mul_(0.5)  # in-place change -> _version bump
+        out2 = r(m, T(rays, dev), noise=tuple(T(n, dev) for n in noise))
+    sc2 = copy.copy(sc)
+    sc2.latent = sc.latent * np.float32(0.5)
+    ref2 = run_oracle(sc2, w, rays, K, NC, G, noise)
+    agree(out2.fine.rgb.cpu().numpy()[0], ref2["rgb"])
+    assert not torch.equal(out1.fine.rgb, out2.fine.rgb)
