@@ -46,6 +46,8 @@ _I64, _I32, _U64, _P = C.c_int64, C.c_int32, C.c_uint64, C.c_void_p
 SYMBOLS = {
     "diner_last_error": (C.c_char_p, []),
     "diner_version": (C.c_int, []),
+    "diner_gen_rays": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
+    "diner_depth2normal": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "diner_pack_maps": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "diner_pack_latent": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "diner_mlp_packed_floats": (_I64, []),

@@ -32,6 +32,8 @@ int launch_pack_maps(const float *, const float *, const float *, int64_t, int, 
 int launch_pack_latent(const float *, int64_t, int, int, int, float *, hipStream_t);
 int launch_pack_mlp(const DinerMlpRaw &, float *, hipStream_t);
 int64_t mlp_packed_floats();
+int launch_gen_rays(const float *, const float *, const float *, const float *, int, int, int, float *, hipStream_t);
+int launch_depth2normal(const float *, const float *, int, int, int, float *, hipStream_t);
 int launch_linz_maps(const float *, int64_t, const float *, float *, hipStream_t);
 int launch_sampler(const DinerScene &, const float *, int64_t, const DinerSamplerCfg &, const float *, const float *,
                    const float *, const float *, uint64_t, float *, float *, float *, hipStream_t);
@@ -79,6 +81,22 @@ extern "C" {
 
 const char *diner_last_error(void) { return g_err; }
 int diner_version(void) { return 1; }
+
+int diner_gen_rays(const float *extrinsics, const float *intrinsics, const float *z_near, const float *z_far, int32_t B,
+                   int32_t H, int32_t W, float *rays_out, void *stream)
+{
+    if (B < 0 || H <= 0 || W <= 0) return bad("gen_rays: bad size");
+    if (B > 0 && (!extrinsics || !intrinsics || !z_near || !z_far || !rays_out)) return bad("gen_rays: NULL pointer");
+    return launch_gen_rays(extrinsics, intrinsics, z_near, z_far, B, H, W, rays_out, (hipStream_t)stream);
+}
+
+int diner_depth2normal(const float *dmap, const float *intrinsics, int32_t N, int32_t H, int32_t W, float *normals_out,
+                       void *stream)
+{
+    if (N < 0 || H <= 0 || W <= 0) return bad("depth2normal: bad size");
+    if (N > 0 && (!dmap || !intrinsics || !normals_out)) return bad("depth2normal: NULL pointer");
+    return launch_depth2normal(dmap, intrinsics, N, H, W, normals_out, (hipStream_t)stream);
+}
 
 int diner_pack_maps(const float *depths, const float *depths_std, const float *normals, int64_t N, int32_t H,
                     int32_t W, float *maps_out, void *stream)

@@ -86,6 +86,16 @@ typedef struct DinerSamplerCfg {
 const char *diner_last_error(void);
 int diner_version(void);
 
+/* ---- adjacent per-image producers, one thread per pixel ---------- */
+/* gen_rays (src/util/cam_geometry.py:36-79): extrinsics [B,4,4] world->camera, intrinsics [B,3,3],
+ * z_near/z_far [B] -> rays [B,H,W,8] (pixel-centre rays: origin, unit direction, near, far). */
+int diner_gen_rays(const float *extrinsics, const float *intrinsics, const float *z_near, const float *z_far,
+                   int32_t B, int32_t H, int32_t W, float *rays_out, void *stream);
+/* depth2normal (src/util/depth2normal.py:7-87): dmap [N,1,H,W], K [N,3,3] -> normals [N,3,H,W]
+ * (central differences of the re-projected depth map + the reference's hole clean-up). */
+int diner_depth2normal(const float *dmap, const float *intrinsics, int32_t N, int32_t H, int32_t W,
+                       float *normals_out, void *stream);
+
 /* ---- once per encode(): re-pack the model's maps for the kernels ----------------------- */
 /* depths, depths_std [N,1,H,W], normals [N,3,H,W] (N = SB*NV) -> maps [N,H,W,8] */
 int diner_pack_maps(const float *depths, const float *depths_std, const float *normals,

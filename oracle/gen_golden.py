@@ -62,10 +62,47 @@ def input_digests(sc, w, rays, noise):
                 rays=digest(rays), noise=digest(*noise))
 
 
+def glue_inputs():
+    """Inputs of the adjacent per-image producers (gen_rays, depth2normal): two cameras, depth maps with
+    background, holes and a pixel on the image border."""
+    rs = np.random.RandomState(77)
+    H, W = 20, 24
+    ext = np.stack([synth.look_at_origin_w2c(0.3, 1.75), synth.look_at_origin_w2c(-0.45, 1.6)])
+    k = np.stack([synth.intrinsics(W, H), synth.intrinsics(W, H)])
+    k[1, 0, 0] *= 0.9
+    k[1, 0, 2] += 1.25
+    k[1, 1, 2] -= 0.75
+    near, far = np.array([1.0, 0.321], np.float32), np.array([2.5, 1.204], np.float32)
+    depth = np.stack([synth.sphere_zdepth(ext[i], k[i], W, H, 0.45) for i in range(2)])[:, None]
+    depth = (depth * (1 + 0.02 * rs.standard_normal(depth.shape)) * (depth > 0)).astype(np.float32)
+    depth[0, 0, 9:11, 11:13] = 0      # a hole inside the object
+    depth[1, 0, 0, :] = 1.3           # a valid row on the image border
+    return dict(extrinsics=ext.astype(np.float32), intrinsics=k.astype(np.float32), z_near=near, z_far=far, H=H, W=W,
+                dmap=depth)
+
+
+def gen_glue(out_dir):
+    import torch
+    from oracle import ref_harness as rh
+    rh.import_reference()
+    from src.util.cam_geometry import gen_rays
+    from src.util.depth2normal import depth2normal
+    g = glue_inputs()
+    t = torch.from_numpy
+    rays = gen_rays(t(g["extrinsics"]), t(g["intrinsics"]), g["W"], g["H"], t(g["z_near"]), t(g["z_far"])).numpy()
+    normals = depth2normal(t(g["dmap"]), t(g["intrinsics"])).numpy()
+    np.savez_compressed(out_dir / "glue.npz", digests=json.dumps(dict(inputs=digest(*[g[k] for k in ("extrinsics", "intrinsics", "z_near", "z_far", "dmap")]))),
+                        rays=rays, normals=normals)
+    print(f"glue: rays {rays.shape} normals {normals.shape} nan={np.isnan(normals).sum()}")
+
+
 def main():
     from oracle import ref_harness as rh
     out_dir = ROOT / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
+    gen_glue(out_dir)
+    if "--glue-only" in sys.argv:
+        return
     for name, cfg in CASES.items():
         t0 = time.time()
         sc, w, rays, noise = case_inputs(cfg)

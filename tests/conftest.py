@@ -10,7 +10,7 @@ if str(ROOT) not in sys.path:
     sys.path.insert(0, str(ROOT))
 
 GOLDEN_DIR = ROOT / "tests" / "golden"
-GOLDEN_NAMES = sorted(p.stem for p in GOLDEN_DIR.glob("*.npz"))
+GOLDEN_NAMES = sorted(p.stem for p in GOLDEN_DIR.glob("g[0-9]*.npz"))
 
 
 def pytest_configure(config):
