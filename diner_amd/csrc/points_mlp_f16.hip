@@ -269,7 +269,7 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
     PHASE(PH_BARRIER)
     int cur_phase = PH_GEOM;
     (void)cur_phase;
-    __shared__ h8 lds[2 * UNITS + TILE_P * 2 + BIAS_FLOATS / 4];  // A_hi | A_lo | one Tap per row | biases (ONE array)
+    __shared__ h8 lds[2 * UNITS + TILE_P * 2 + BIAS_FLOATS / 4 + 1];  // A_hi | A_lo | one Tap per row | biases | pacing flag (ONE array)
     h8 *Ahi8 = lds, *Alo8 = lds + UNITS;
     _Float16 *Ahi = (_Float16 *)Ahi8, *Alo = (_Float16 *)Alo8;
     Tap *taps = (Tap *)(lds + 2 * UNITS);
@@ -299,22 +299,28 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
     // every tile together.  They all stream the same 1 MiB weight layers in the same order; kept in step, one
     // fetch from the Infinity Cache serves the whole XCD through its L2, while drifting apart they each
     // miss (measured: L2 hit rate 56 % unpaced).  A monotonic counter per group, bounded polling: a
-    // workgroup that times out simply goes on, so residency or placement can never turn this into a hang.
+    // workgroup that times out stops pacing for the rest of the launch and simply goes on, so residency or
+    // placement can never turn this into a hang (or, on a shared GPU, into a repeated stall).
     unsigned int *pace = (unsigned int *)scratch + (blockIdx.x & 7) * 32;
     const unsigned int group = (gridDim.x + 7 - (blockIdx.x & 7)) / 8 * gridDim.y;  // workgroups with this residue
     const int64_t full_rounds = tiles / gridDim.x;                                   // rounds in which every workgroup has a tile
     int64_t round = 0;
+    bool pace_on = true;
+    volatile int *pace_flag = (volatile int *)(lds + 2 * UNITS + TILE_P * 2 + BIAS_FLOATS / 4);  // one LDS word
     for (int64_t tile = slot; tile < tiles; tile += gridDim.x, ++round) {
-        if (round < full_rounds && group > 1) {
+        if (pace_on && round < full_rounds && group > 1) {
             if (tid == 0) {
                 __hip_atomic_fetch_add(pace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 const unsigned int want = (unsigned int)(round + 1) * group;
-                for (int spin = 0; spin < 20000; ++spin) {
+                int spin = 0;
+                for (; spin < 4000; ++spin) {
                     if (__hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
                     __builtin_amdgcn_s_sleep(8);
                 }
+                pace_flag[0] = spin < 4000;  // timed out once (peers not co-resident?): stop pacing, keep computing
             }
             __syncthreads();
+            pace_on = pace_flag[0] != 0;
         }
         int64_t p = tile * TILE_P + row;
         if (p > P - 1) p = P - 1;  // tail tile: duplicate the last point, masked at the store
