@@ -118,21 +118,26 @@ __device__ __forceinline__ void fill_up_and_sort(float *zs, int K, float near, f
 
 // stratified candidate j of a ray (sample_coarse, :53-60): t_j = linspace(0, 1-1/NC, NC)[j] + u/NC,
 // z = near*(1-t) + far*t; torch.linspace in fp32 evaluates symmetrically from both ends.
-__device__ __forceinline__ float candidate_z(int j, int NC, float near, float far, const float *u_row, int64_t gray, uint2 key)
+struct CandGeo { float end, step, lstep; };
+__device__ __forceinline__ CandGeo cand_geo(int NC)
 {
     const double stepd = 1.0 / (double)NC;
-    const float end = (float)(1.0 - stepd), step = (float)stepd;
-    const float lstep = end / (float)(NC - 1);
-    float u;
-    if (u_row) u = u_row[j];
-    else {
-        const uint4 r = philox4x32(make_uint4((uint32_t)j >> 2, 0u, (uint32_t)gray, (uint32_t)(gray >> 32)), key);
-        const uint32_t sel = (j & 3) == 0 ? r.x : (j & 3) == 1 ? r.y : (j & 3) == 2 ? r.z : r.w;
-        u = u01(sel);
-    }
-    float t = (NC == 1) ? 0.0f : (j < NC / 2 ? lstep * (float)j : end - lstep * (float)(NC - j - 1));
-    t = t + u * step;
+    CandGeo g;
+    g.end = (float)(1.0 - stepd); g.step = (float)stepd; g.lstep = g.end / (float)(NC - 1);
+    return g;
+}
+__device__ __forceinline__ float candidate_from_u(int j, int NC, float near, float far, float u, const CandGeo &g)
+{
+    float t = (NC == 1) ? 0.0f : (j < NC / 2 ? g.lstep * (float)j : g.end - g.lstep * (float)(NC - j - 1));
+    t = t + u * g.step;
     return near * (1.0f - t) + far * t;
+}
+// in-kernel noise of candidate j: one Philox call yields the 4 candidates {lane + 64*(4g .. 4g+3)} of a lane
+__device__ __forceinline__ float candidate_u_philox(int j, int64_t gray, uint2 key)
+{
+    const int comp = (j >> 6) & 3;
+    const uint4 r = philox4x32(make_uint4((uint32_t)((j & 63) | ((j >> 8) << 6)), 0u, (uint32_t)gray, (uint32_t)(gray >> 32)), key);
+    return u01(comp == 0 ? r.x : comp == 1 ? r.y : comp == 2 ? r.z : r.w);
 }
 
 template <int CPL>  // candidates per lane: NC <= 64*CPL
@@ -153,14 +158,23 @@ __global__ __launch_bounds__(64) void sampler_kernel(
 
     // ---- candidates (sample_coarse, :53-60) ---------------------------------------------------
     float z[CPL], L[CPL];
+    {
+        const CandGeo cg = cand_geo(NC);
 #pragma unroll
-    for (int c = 0; c < CPL; ++c) {
-        const int j = c * 64 + lane;
-        L[c] = 0.0f;
-        z[c] = 0.0f;
-        if (j >= NC) continue;
-        z[c] = z_cand ? z_cand[gray * NC + j]
-                      : candidate_z(j, NC, near, far, u_coarse ? u_coarse + gray * NC : nullptr, gray, key);
+        for (int g4 = 0; g4 < CPL / 4; ++g4) {  // 4 chunks (candidates lane + 64*(4*g4 + 0..3)) share one Philox call
+            uint4 rnd = make_uint4(0u, 0u, 0u, 0u);
+            if (!z_cand && !u_coarse) rnd = philox4x32(make_uint4((uint32_t)(lane | (g4 << 6)), 0u, (uint32_t)gray, (uint32_t)(gray >> 32)), key);
+#pragma unroll
+            for (int cc = 0; cc < 4; ++cc) {
+                const int c = g4 * 4 + cc, j = c * 64 + lane;
+                L[c] = 0.0f;
+                z[c] = 0.0f;
+                if (j >= NC) continue;
+                if (z_cand) { z[c] = z_cand[gray * NC + j]; continue; }
+                const float u = u_coarse ? u_coarse[gray * NC + j] : u01(cc == 0 ? rnd.x : cc == 1 ? rnd.y : cc == 2 ? rnd.z : rnd.w);
+                z[c] = candidate_from_u(j, NC, near, far, u, cg);
+            }
+        }
     }
 
     // ---- per-view surface likelihood, max over views (:94-129) ----------------------------------
@@ -229,7 +243,11 @@ __global__ __launch_bounds__(64) void sampler_kernel(
     int n_kept = 0;
     if (keep > 0) {
         uint32_t T = 0;
-        for (int b = 29; b >= 0; --b) {
+        int n_nz = 0;
+#pragma unroll
+        for (int c = 0; c < CPL; ++c) n_nz += __popcll(__ballot(L[c] > 0.0f));
+        // fewer non-zero likelihoods than slots: everything non-zero is kept, no threshold to search for
+        for (int b = (n_nz <= keep) ? -1 : 29; b >= 0; --b) {
             const uint32_t cand = T | (1u << b);
             int cnt = 0;
 #pragma unroll
@@ -286,7 +304,8 @@ __global__ __launch_bounds__(256) void sample_coarse_kernel(const float *__restr
     const int64_t ray = i / NC;
     const int j = (int)(i - ray * NC);
     const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
-    z_out[i] = candidate_z(j, NC, rays[ray * 8 + 6], rays[ray * 8 + 7], u_coarse ? u_coarse + ray * NC : nullptr, ray, key);
+    const float u = u_coarse ? u_coarse[ray * NC + j] : candidate_u_philox(j, ray, key);
+    z_out[i] = candidate_from_u(j, NC, rays[ray * 8 + 6], rays[ray * 8 + 7], u, cand_geo(NC));
 }
 
 __global__ __launch_bounds__(64) void fill_up_kernel(const float *__restrict__ rays, const float *__restrict__ z_in,
