@@ -49,6 +49,7 @@ SYMBOLS = {
     "diner_gen_rays": (C.c_int, [_P, _P, _P, _P, _I32, _I32, _I32, _P, _P]),
     "diner_depth2normal": (C.c_int, [_P, _P, _I32, _I32, _I32, _P, _P]),
     "diner_pack_maps": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
+    "diner_pack_maps_from_depth": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "diner_pack_latent": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "diner_mlp_packed_floats": (_I64, []),
     "diner_pack_mlp": (C.c_int, [C.POINTER(DinerMlpRaw), _P, _P]),

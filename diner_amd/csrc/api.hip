@@ -34,6 +34,7 @@ int launch_pack_mlp(const DinerMlpRaw &, float *, hipStream_t);
 int64_t mlp_packed_floats();
 int launch_gen_rays(const float *, const float *, const float *, const float *, int, int, int, float *, hipStream_t);
 int launch_depth2normal(const float *, const float *, int, int, int, float *, hipStream_t);
+int launch_pack_maps_from_depth(const float *, const float *, const float *, int, int, int, float *, hipStream_t);
 int launch_linz_maps(const float *, int64_t, const float *, float *, hipStream_t);
 int launch_sampler(const DinerScene &, const float *, int64_t, const DinerSamplerCfg &, const float *, const float *,
                    const float *, const float *, uint64_t, float *, float *, float *, hipStream_t);
@@ -104,6 +105,14 @@ int diner_pack_maps(const float *depths, const float *depths_std, const float *n
     if (!depths || !depths_std || !normals || !maps_out) return bad("pack_maps: NULL pointer");
     if (N < 0 || H <= 0 || W <= 0) return bad("pack_maps: bad size");
     return launch_pack_maps(depths, depths_std, normals, N, H, W, maps_out, (hipStream_t)stream);
+}
+
+int diner_pack_maps_from_depth(const float *depths, const float *depths_std, const float *intrinsics, int64_t N, int32_t H,
+                               int32_t W, float *maps_out, void *stream)
+{
+    if (!depths || !depths_std || !intrinsics || !maps_out) return bad("pack_maps_from_depth: NULL pointer");
+    if (N < 0 || N > 0x7fffffff || H <= 0 || W <= 0) return bad("pack_maps_from_depth: bad size");
+    return launch_pack_maps_from_depth(depths, depths_std, intrinsics, (int)N, H, W, maps_out, (hipStream_t)stream);
 }
 
 int diner_pack_latent(const float *latent_nchw, int64_t N, int32_t C, int32_t h, int32_t w, float *latent_out,

@@ -86,6 +86,41 @@ __global__ void depth2normal_kernel(const float *__restrict__ dmap, const float 
     o[0] = nx; o[(int64_t)H * W] = ny; o[2 * (int64_t)H * W] = nz;
 }
 
+// depth2normal fused into the map packing: depths/depths_std [N,1,H,W] + K [N,3,3]
+// -> maps [N,H,W,8] = nx ny nz depth | sigma 0 0 0 without materialising the NCHW normal tensor.
+__global__ void pack_maps_from_depth_kernel(const float *__restrict__ dmap, const float *__restrict__ dstd,
+                                            const float *__restrict__ intr, int N, int H, int W, float4 *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)N * H * W) return;
+    const int n = (int)(i / ((int64_t)H * W));
+    const int p = (int)(i - (int64_t)n * H * W), y = p / W, x = p - y * W;
+    const float *d = dmap + (int64_t)n * H * W, *Kk = intr + n * 9;
+    const float fx = Kk[0], fy = Kk[4], cx = Kk[2], cy = Kk[5];
+    float nx, ny, nz;
+    int offy, offx;
+    d2n_raw(d, H, W, fx, fy, cx, cy, x, y, nx, ny, nz, offy, offx);
+    if (offy != 0 || offx != 0) {
+        int qy = y + offy, qx = x + offx, t0, t1;
+        qy = qy < 0 ? 0 : (qy > H - 1 ? H - 1 : qy);
+        qx = qx < 0 ? 0 : (qx > W - 1 ? W - 1 : qx);
+        d2n_raw(d, H, W, fx, fy, cx, cy, qx, qy, nx, ny, nz, t0, t1);
+    }
+    if (d[p] == 0.0f) { nx = 0.0f; ny = 0.0f; nz = 0.0f; }
+    out[i * 2 + 0] = make_float4(nx, ny, nz, d[p]);
+    out[i * 2 + 1] = make_float4(dstd[i], 0.f, 0.f, 0.f);
+}
+
+int launch_pack_maps_from_depth(const float *dmap, const float *dstd, const float *intr, int N, int H, int W, float *out,
+                                hipStream_t st)
+{
+    const int64_t total = (int64_t)N * H * W;
+    if (total == 0) return DINER_OK;
+    hipLaunchKernelGGL(pack_maps_from_depth_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dmap, dstd, intr, N,
+                       H, W, (float4 *)out);
+    return check_launch("pack_maps_from_depth_kernel");
+}
+
 int launch_gen_rays(const float *extr, const float *intr, const float *zn, const float *zf, int B, int H, int W, float *rays,
                     hipStream_t st)
 {

@@ -47,3 +47,15 @@ def depth2normal(dmap, K):
     check(_lib.lib().diner_depth2normal(d.data_ptr(), k.data_ptr(), N, H, W, out.data_ptr(), _st(d.device)),
           "diner_depth2normal")
     return out
+
+
+@torch.no_grad()
+def pack_maps_from_depth(depths, depths_std, intrinsics):
+    """depth2normal fused into the renderer's map packing: depths, depths_std [SB,NV,1,H,W], intrinsics
+    [SB,NV,3,3] -> packed maps [SB,NV,H,W,8] (nx ny nz depth | sigma 0 0 0), the layout ``DinerScene.maps`` takes."""
+    d, s, k = _f(depths), _f(depths_std), _f(intrinsics)
+    SB, NV, _, H, W = d.shape
+    out = torch.empty((SB, NV, H, W, 8), dtype=torch.float32, device=d.device)
+    check(_lib.lib().diner_pack_maps_from_depth(d.data_ptr(), s.data_ptr(), k.data_ptr(), SB * NV, H, W, out.data_ptr(),
+                                                _st(d.device)), "diner_pack_maps_from_depth")
+    return out

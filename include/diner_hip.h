@@ -100,6 +100,10 @@ int diner_depth2normal(const float *dmap, const float *intrinsics, int32_t N, in
 /* depths, depths_std [N,1,H,W], normals [N,3,H,W] (N = SB*NV) -> maps [N,H,W,8] */
 int diner_pack_maps(const float *depths, const float *depths_std, const float *normals,
                     int64_t N, int32_t H, int32_t W, float *maps_out, void *stream);
+/* the same with depth2normal (src/util/depth2normal.py:7-87, called at src/models/pixelnerf.py:45) fused in:
+ * depths, depths_std [N,1,H,W], intrinsics [N,3,3] -> maps [N,H,W,8]; no NCHW normal tensor is materialised */
+int diner_pack_maps_from_depth(const float *depths, const float *depths_std, const float *intrinsics,
+                               int64_t N, int32_t H, int32_t W, float *maps_out, void *stream);
 /* latent [N,C,h,w] (NCHW, src/models/image_encoder.py:271) -> [N,h,w,C] with the channel order
  * the MLP kernel stages into LDS (C = 512) */
 int diner_pack_latent(const float *latent_nchw, int64_t N, int32_t C, int32_t h, int32_t w,

@@ -48,3 +48,27 @@ def test_hip_gen_rays_and_depth2normal(glue):
     np.testing.assert_allclose(np.nan_to_num(n), np.nan_to_num(gold["normals"]), rtol=0, atol=2e-5)
     bg = g["dmap"][:, 0] == 0
     assert np.all(n.transpose(0, 2, 3, 1)[bg] == 0)
+
+
+@pytest.mark.gpu
+def test_fused_depth2normal_packing_equals_two_step(glue):
+    """diner_pack_maps_from_depth == depth2normal followed by diner_pack_maps (bit for bit)."""
+    import ctypes as C
+
+    import torch
+    from diner_amd import _lib
+    from diner_amd import glue as hip
+    g, _ = glue
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = t(g["dmap"])[None]                                            # [1,N,1,H,W]
+    std = torch.rand_like(d) * 0.01
+    k = t(g["intrinsics"])[None]
+    fused = hip.pack_maps_from_depth(d, std, k)
+    n = hip.depth2normal(d[0], k[0])
+    N, _, H, W = d[0].shape
+    two = torch.empty((1, N, H, W, 8), device=dev)
+    _lib.check(_lib.lib().diner_pack_maps(d.data_ptr(), std.data_ptr(), n.data_ptr(), N, H, W, two.data_ptr(),
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), "diner_pack_maps")
+    torch.cuda.synchronize()
+    assert torch.equal(torch.nan_to_num(fused), torch.nan_to_num(two))
