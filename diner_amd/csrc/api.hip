@@ -32,6 +32,16 @@ int launch_pack_maps(const float *, const float *, const float *, int64_t, int, 
 int launch_pack_latent(const float *, int64_t, int, int, int, float *, hipStream_t);
 int launch_pack_mlp(const DinerMlpRaw &, float *, hipStream_t);
 int64_t mlp_packed_floats();
+int launch_train_gemm(const float *, const float *, const float *, const float *, float *, int64_t, int, int, int64_t, int64_t, int64_t,
+                      int64_t, int64_t, int64_t, int, int, int, int, int64_t, hipStream_t);
+int launch_train_colsum(const float *, int64_t, int, int64_t, float *, hipStream_t);
+int launch_train_point_inputs(const DinerScene &, const float *, const float *, const float *, int64_t, int, int, float *, float *,
+                              float *, hipStream_t);
+int launch_train_bilinear_scatter(const float *, const float *, int64_t, int, int, int, int, int, float *, hipStream_t);
+int launch_train_view_mean(const float *, int64_t, int, float *, int, hipStream_t);
+int launch_train_head(const float *, const float *, const float *, int64_t, float *, int, hipStream_t);
+int launch_train_composite_bwd(const float *, const float *, const float *, const float *, const float *, const float *, int64_t, int,
+                               int, float *, hipStream_t);
 int launch_gen_rays(const float *, const float *, const float *, const float *, int, int, int, float *, hipStream_t);
 int launch_depth2normal(const float *, const float *, int, int, int, float *, hipStream_t);
 int launch_pack_maps_from_depth(const float *, const float *, const float *, int, int, int, float *, hipStream_t);
@@ -198,6 +208,61 @@ int diner_composite(const float *rays, const float *z, const float *rgbsigma, in
     if (N < 0 || K < 1) return bad("composite: bad N / K");
     if (N > 0 && (!rays || !z || !rgbsigma || !rgb_out || !depth_out)) return bad("composite: NULL pointer");
     return launch_composite(rays, z, rgbsigma, N, K, white_bkgd, rgb_out, depth_out, weights_out, (hipStream_t)stream);
+}
+
+/* ---- training path building blocks (train.hip) ------------------------------------------------ */
+int diner_train_gemm(const float *A, const float *B, const float *bias, const float *S, float *C, int64_t M, int32_t N, int32_t K,
+                     int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc, int64_t lds, int32_t relu_a, int32_t relu_b,
+                     int32_t accumulate, int32_t atomic, int64_t k_chunk, void *stream)
+{
+    if (!A || !B || !C) return bad("train_gemm: NULL pointer");
+    if (M < 0 || N <= 0 || K <= 0 || (N & 3) || (k_chunk & 15)) return bad("train_gemm: bad size (N % 4, k_chunk % 16 must be 0)");
+    return launch_train_gemm(A, B, bias, S, C, M, N, K, sam, sak, sbk, sbn, ldc, lds, relu_a, relu_b, accumulate, atomic, k_chunk,
+                             (hipStream_t)stream);
+}
+
+int diner_train_colsum(const float *dY, int64_t M, int32_t N, int64_t ld, float *db, void *stream)
+{
+    if (!dY || !db || M < 0 || N <= 0) return bad("train_colsum: bad argument");
+    return launch_train_colsum(dY, M, N, ld, db, (hipStream_t)stream);
+}
+
+int diner_train_point_inputs(const DinerScene *scene, const float *latent_nchw, const float *rays, const float *z, int64_t NR,
+                             int32_t K, int32_t sb, float *in56, float *zlat, float *taps, void *stream)
+{
+    int rc;
+    if ((rc = check_scene(scene, false))) return rc;
+    if (!latent_nchw || !rays || !z || !in56 || !zlat || !taps) return bad("train_point_inputs: NULL pointer");
+    if (scene->C != DINER_D_LATENT || scene->h <= 0 || scene->w <= 0 || sb < 0 || sb >= scene->SB) return bad("train_point_inputs: bad scene");
+    return launch_train_point_inputs(*scene, latent_nchw, rays, z, NR, K, sb, in56, zlat, taps, (hipStream_t)stream);
+}
+
+int diner_train_bilinear_scatter(const float *dz, const float *taps, int64_t P, int32_t C, int32_t h, int32_t w, int32_t NV, int32_t sb,
+                                 float *dlatent_nchw, void *stream)
+{
+    if (!dz || !taps || !dlatent_nchw) return bad("train_bilinear_scatter: NULL pointer");
+    return launch_train_bilinear_scatter(dz, taps, P, C, h, w, NV, sb, dlatent_nchw, (hipStream_t)stream);
+}
+
+int diner_train_view_mean(const float *x, int64_t PC, int32_t NV, float *out, int32_t backward, void *stream)
+{
+    if (!x || !out || NV < 1) return bad("train_view_mean: bad argument");
+    return launch_train_view_mean(x, PC, NV, out, backward, (hipStream_t)stream);
+}
+
+int diner_train_head(const float *out, const float *rgbsigma, const float *d_rgbsigma, int64_t n4, float *result, int32_t backward,
+                     void *stream)
+{
+    if (!out || !result || (backward && (!rgbsigma || !d_rgbsigma))) return bad("train_head: NULL pointer");
+    return launch_train_head(out, rgbsigma, d_rgbsigma, n4, result, backward, (hipStream_t)stream);
+}
+
+int diner_composite_backward(const float *rays, const float *z, const float *rgbsigma, const float *d_rgb, const float *d_depth,
+                             const float *d_weights, int64_t N, int32_t K, int32_t white_bkgd, float *d_rgbsigma, void *stream)
+{
+    if (N < 0 || K < 1) return bad("composite_backward: bad N / K");
+    if (N > 0 && (!rays || !z || !rgbsigma || !d_rgb || !d_rgbsigma)) return bad("composite_backward: NULL pointer");
+    return launch_train_composite_bwd(rays, z, rgbsigma, d_rgb, d_depth, d_weights, N, K, white_bkgd, d_rgbsigma, (hipStream_t)stream);
 }
 
 int64_t diner_render_workspace_floats(int64_t SB, int64_t NR, int32_t K, int32_t NV, int32_t precision)

@@ -1,0 +1,364 @@
+// Training path: forward with saved activations + backward of
+//   NeRFRendererDGS.composite   reference src/models/nerf_renderer.py:286-365
+//   PixelNeRF.forward           reference src/models/pixelnerf.py:55-145
+//   ResnetFC.forward            reference src/models/resnetfc.py:129-159
+// as used by DINER.calc_losses (src/models/diner.py:217-290): gradients w.r.t. the fusion-MLP parameters and
+// the encoder's latent maps (the sampler is @torch.no_grad in the reference, points/viewdirs carry no grad).
+//
+// Unlike the fused inference kernels this path is layer by layer: every layer's input must be kept for the
+// weight gradients anyway, so activations live in HBM as row-major [rows, 512] fp32 matrices (rows = point x
+// view, ~10 GB for a 4096-ray x 40-sample x 4-view step -- 288 GB of HBM make that a non-issue) and all linear
+// algebra is ONE exact fp32 MFMA GEMM kernel (v_mfma_f32_32x32x2_f32) with stride-described operands:
+//     C[m][n] (+)= sum_k opA(A[m*sam + k*sak]) * opB(B[k*sbk + n*sbn])      (+ bias[n]) (* [S[m][n] > 0])
+//   forward      Y  = relu?(X) W^T + b (+ Y)          A = X (k contiguous), B = W (k contiguous)
+//   backward dX  dX = (dY W) * [S > 0] (+ dX)         A = dY (k contiguous), B = W (n contiguous)
+//   backward dW  dW += dY^T relu?(X), split over rows A = dY (m contiguous), B = X (n contiguous), atomic C
+// plus small per-point kernels (inputs/bilinear gather, view mean, head, compositing backward, bilinear
+// scatter-add).  Correctness first: ~40-60 TFLOP/s GEMMs, not the tuned inference path.
+#include "common.hpp"
+
+namespace diner {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+namespace train {
+
+constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;  // LDS tile row stride (floats), 16-byte aligned rows
+
+struct GemmArgs {
+    const float *A, *B, *bias, *S;
+    float *C;
+    int64_t M;
+    int N, K;
+    int64_t sam, sak, sbk, sbn;  // element strides of the logical A[m][k], B[k][n]
+    int64_t ldc, lds_;           // row strides of C and of the mask S
+    int relu_a, relu_b, accumulate, atomic;
+    int64_t k_chunk;             // split-K: blockIdx.z handles k in [z*k_chunk, (z+1)*k_chunk)
+};
+
+// AK: A contiguous along k (sak == 1) else along m (sam == 1).  BN_: B contiguous along n (sbn == 1) else along k.
+template <bool AK, bool BNC>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
+{
+    __shared__ float As[BK][LDT], Bs[BK][LDT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t m0 = (int64_t)blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int64_t kbeg = (int64_t)blockIdx.z * g.k_chunk;
+    const int64_t kend = kbeg + g.k_chunk < g.K ? kbeg + g.k_chunk : g.K;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
+        // ---- stage A tile: As[k][m] ----
+        if (AK) {  // float4 along k: thread -> (m = tid/4, k quad = tid%4)
+            const int m = tid >> 2, kq = (tid & 3) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (m0 + m < g.M && k0 + kq < kend) v = *(const f32x4 *)(g.A + (m0 + m) * g.sam + (k0 + kq));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) As[kq + i][m] = g.relu_a ? (v[i] > 0.f ? v[i] : 0.f) : v[i];
+        } else {   // float4 along m: thread -> (k = tid/16, m quad = tid%16)
+            const int k = tid >> 4, mq = (tid & 15) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + k < kend && m0 + mq < g.M) v = *(const f32x4 *)(g.A + (k0 + k) * g.sak + (m0 + mq));
+            if (g.relu_a) { for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f; }
+            *(f32x4 *)&As[k][mq] = v;
+        }
+        // ---- stage B tile: Bs[k][n] ----
+        if (BNC) {
+            const int k = tid >> 4, nq = (tid & 15) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (k0 + k < kend && n0 + nq < g.N) v = *(const f32x4 *)(g.B + (k0 + k) * g.sbk + (n0 + nq));
+            if (g.relu_b) { for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f; }
+            *(f32x4 *)&Bs[k][nq] = v;
+        } else {
+            const int n = tid >> 2, kq = (tid & 3) * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n0 + n < g.N && k0 + kq < kend) v = *(const f32x4 *)(g.B + (int64_t)(n0 + n) * g.sbn + (k0 + kq));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) Bs[kq + i][n] = g.relu_b ? (v[i] > 0.f ? v[i] : 0.f) : v[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = As[kk + (lane >> 5)][wm + (lane & 31)], b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5) ----
+    const int n = n0 + wn + (lane & 31);
+    if (n >= g.N) return;
+    const float bias = (g.bias && blockIdx.z == 0) ? g.bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int64_t m = m0 + wm + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+        if (m >= g.M) continue;
+        float v = acc[i] + bias;
+        if (g.S) v = g.S[m * g.lds_ + n] > 0.0f ? v : 0.0f;
+        float *c = g.C + m * g.ldc + n;
+        if (g.atomic) atomicAdd(c, v);
+        else *c = g.accumulate ? *c + v : v;
+    }
+}
+
+int launch_gemm(const GemmArgs &g, hipStream_t st)
+{
+    if (g.M == 0 || g.N == 0) return DINER_OK;
+    const int64_t kc = g.k_chunk > 0 ? g.k_chunk : g.K;
+    GemmArgs a = g;
+    a.k_chunk = kc;
+    const dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN), (unsigned)((g.K + kc - 1) / kc));
+    const bool ak = g.sak == 1, bnc = g.sbn == 1;
+    if (!ak && g.sam != 1) { set_error("gemm: A must be contiguous along m or k"); return DINER_E_INVALID; }
+    if (!bnc && g.sbk != 1) { set_error("gemm: B must be contiguous along k or n"); return DINER_E_INVALID; }
+    if (ak && bnc) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, st, a);
+    else if (ak && !bnc) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, st, a);
+    else if (!ak && bnc) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, st, a);
+    return check_launch("train::gemm_kernel");
+}
+
+// column sums: db[n] += sum_m dY[m][n]  (one block per 64 columns, rows strided over the block, atomic tail)
+__global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ dY, int64_t M, int N, int64_t ld, float *__restrict__ db)
+{
+    __shared__ float part[4][64];
+    const int c = threadIdx.x & 63, r = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    float s = 0.f;
+    const int64_t rows_per = (M + gridDim.y - 1) / gridDim.y, beg = blockIdx.y * rows_per, end = beg + rows_per < M ? beg + rows_per : M;
+    if (n < N)
+        for (int64_t m = beg + r; m < end; m += 4) s += dY[m * ld + n];
+    part[r][c] = s;
+    __syncthreads();
+    if (r == 0 && n < N) atomicAdd(db + n, part[0][c] + part[1][c] + part[2][c] + part[3][c]);
+}
+
+// ---- per-(view, point) MLP inputs: in55 (padded to 56), bilinear latent z, and the footprint ------------------
+// rows are view-major: row = v*P + p.  latent is the reference's NCHW tensor [NV,C,h,w] (its gradient has
+// that layout too).  taps_out [R,8] = 4 texel indices (y*w+x, as int bits) + 4 weights.
+__global__ __launch_bounds__(64) void point_inputs_kernel(DinerScene s, const float *__restrict__ latent_nchw,
+                                                          const float *__restrict__ rays, const float *__restrict__ zsamp,
+                                                          int64_t NR, int K, int sb, float *__restrict__ in56,
+                                                          float *__restrict__ zlat, float *__restrict__ taps_out)
+{
+    const int64_t P = NR * (int64_t)K, row = blockIdx.x;
+    const int v = (int)(row / P);
+    const int64_t p = row - (int64_t)v * P;
+    const int lane = threadIdx.x;
+    const float *rp = rays + ((int64_t)sb * NR + p / K) * 8;
+    const float zz = zsamp[(int64_t)sb * P + p];
+    const float dwx = rp[3], dwy = rp[4], dwz = rp[5];
+    const float wx = rp[0] + zz * dwx, wy = rp[1] + zz * dwy, wz = rp[2] + zz * dwz;  // nerf_renderer.py:304
+    const View vw = load_view(s, sb, v);
+    float px, py, pz, u, w, dcx, dcy, dcz;
+    project(vw, s.image_w, s.image_h, wx, wy, wz, px, py, pz, u, w);                  // pixelnerf.py:91-93,105-108
+    rotate(vw, dwx, dwy, dwz, dcx, dcy, dcz);
+    const float4 *tex = (const float4 *)s.maps + ((int64_t)sb * s.NV + v) * s.H * s.W * 2;
+    const int ddx = safe_idx(__builtin_rintf(clipf(unnorm(u, (float)s.W / 2.0f), (float)(s.W - 1))), s.W);
+    const int ddy = safe_idx(__builtin_rintf(clipf(unnorm(w, (float)s.H / 2.0f), (float)(s.H - 1))), s.H);
+    const float delta = tex[((int64_t)ddy * s.W + ddx) * 2].w - pz;
+    if (lane < 56) {
+        const int e = lane;
+        const float half_pi = 1.5707963267948966f;
+        float val;
+        if (e < 3) val = e == 0 ? px : e == 1 ? py : pz;
+        else if (e < 39) { const int j = (e - 3) / 3, i = (e - 3) % 3;
+            val = sinf(__builtin_fmaf(i == 0 ? px : i == 1 ? py : pz, s.freq_factor * (float)(1 << (j >> 1)), (j & 1) ? half_pi : 0.0f)); }
+        else if (e < 42) val = e == 39 ? dcx : e == 40 ? dcy : dcz;
+        else if (e == 42) val = delta;
+        else if (e < 55) { const int j = e - 43;
+            val = sinf(__builtin_fmaf(delta, s.freq_factor * (float)(1 << (j >> 1)), (j & 1) ? half_pi : 0.0f)); }
+        else val = 0.0f;
+        in56[row * 56 + e] = val;
+    }
+    // bilinear / border footprint (image_encoder.py:97-127)
+    const float sxl = ((float)s.w - s.feature_padding * 2.0f) / (float)s.w, syl = ((float)s.h - s.feature_padding * 2.0f) / (float)s.h;
+    const float ix = clipf(unnorm(u * sxl, (float)s.w / 2.0f), (float)(s.w - 1));
+    const float iy = clipf(unnorm(w * syl, (float)s.h / 2.0f), (float)(s.h - 1));
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const float fx = ix - x0f, ex = 1.0f - fx, fy = iy - y0f, ey = 1.0f - fy;
+    const int x0 = safe_idx(x0f, s.w), y0 = safe_idx(y0f, s.h);
+    const bool x1ok = x0 + 1 <= s.w - 1, y1ok = y0 + 1 <= s.h - 1;
+    const int x1 = x1ok ? x0 + 1 : x0, y1 = y1ok ? y0 + 1 : y0;
+    const int o[4] = {y0 * s.w + x0, y0 * s.w + x1, y1 * s.w + x0, y1 * s.w + x1};
+    const float wt[4] = {ey * ex, x1ok ? ey * fx : 0.0f, y1ok ? fy * ex : 0.0f, (x1ok && y1ok) ? fy * fx : 0.0f};
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { taps_out[row * 8 + i] = __int_as_float(o[i]); taps_out[row * 8 + 4 + i] = wt[i]; }
+    }
+    const int64_t plane = (int64_t)s.h * s.w;
+    const float *lat = latent_nchw + ((int64_t)sb * s.NV + v) * s.C * plane;
+    for (int ch = lane; ch < s.C; ch += 64) {
+        const float *pl = lat + ch * plane;
+        zlat[row * s.C + ch] = __builtin_fmaf(pl[o[3]], wt[3], __builtin_fmaf(pl[o[2]], wt[2], __builtin_fmaf(pl[o[1]], wt[1], pl[o[0]] * wt[0])));
+    }
+}
+
+// dlatent[v][ch][tap] += dz[row][ch] * w_tap  (bilinear backward; atomics: several points share a texel)
+__global__ __launch_bounds__(64) void bilinear_scatter_kernel(const float *__restrict__ dz, const float *__restrict__ taps,
+                                                              int64_t P, int C, int h, int w, int NV, int sb,
+                                                              float *__restrict__ dlatent_nchw)
+{
+    const int64_t row = blockIdx.x;
+    const int v = (int)(row / P), lane = threadIdx.x;
+    const int64_t plane = (int64_t)h * w;
+    float *lat = dlatent_nchw + ((int64_t)sb * NV + v) * C * plane;
+    int o[4];
+    float wt[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { o[i] = __float_as_int(taps[row * 8 + i]); wt[i] = taps[row * 8 + 4 + i]; }
+    for (int ch = lane; ch < C; ch += 64) {
+        const float g = dz[row * C + ch];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (wt[i] != 0.0f) atomicAdd(lat + ch * plane + o[i], g * wt[i]);
+    }
+}
+
+// mean over views (resnetfc.py:146-149): x [NV,P,C] -> xbar [P,C];  backward: dx[v] = dxbar / NV
+__global__ void view_mean_kernel(const float *__restrict__ x, int64_t PC, int NV, float *__restrict__ xbar)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= PC) return;
+    float s = x[i];
+    for (int v = 1; v < NV; ++v) s = s + x[(int64_t)v * PC + i];
+    xbar[i] = s / (float)NV;
+}
+__global__ void view_mean_bwd_kernel(const float *__restrict__ dxbar, int64_t PC, int NV, float *__restrict__ dx)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= PC) return;
+    const float g = dxbar[i] / (float)NV;
+    for (int v = 0; v < NV; ++v) dx[(int64_t)v * PC + i] = g;
+}
+
+// head (pixelnerf.py:139-143): out [P,4] -> rgbsigma [P,4];  backward: d_out = d_rgbsigma * (sigmoid', relu')
+__global__ void head_kernel(const float *__restrict__ out, int64_t n4, float *__restrict__ rgbsigma)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float v = out[i];
+    rgbsigma[i] = (i & 3) < 3 ? 1.0f / (1.0f + expf(-v)) : (v > 0.0f ? v : 0.0f);
+}
+__global__ void head_bwd_kernel(const float *__restrict__ out, const float *__restrict__ rgbsigma, const float *__restrict__ d_rgbsigma,
+                                int64_t n4, float *__restrict__ d_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float y = rgbsigma[i], g = d_rgbsigma[i];
+    d_out[i] = (i & 3) < 3 ? g * y * (1.0f - y) : (out[i] > 0.0f ? g : 0.0f);
+}
+
+// compositing backward (nerf_renderer.py:299-301, 341-360), one ray per thread, sequential over K (K <= a few hundred):
+//   alpha_k = 1 - exp(-delta_k relu(sigma_k)), T_k = prod_{i<k}(1 - alpha_i + 1e-10), w_k = alpha_k T_k
+//   rgb = sum w c (+ 1 - sum w), depth = sum w z
+// given d_rgb [N,3], d_depth [N] (and optionally d_weights [N,K]) -> d_rgbsigma [N,K,4].  z carries no gradient.
+__global__ void composite_bwd_kernel(const float *__restrict__ rays, const float *__restrict__ z, const float *__restrict__ rgbsigma,
+                                     const float *__restrict__ d_rgb, const float *__restrict__ d_depth,
+                                     const float *__restrict__ d_weights, int64_t N, int K, int white_bkgd,
+                                     float *__restrict__ d_rgbsigma)
+{
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= N) return;
+    const float far = rays[r * 8 + 7];
+    const float *zr = z + r * K, *cr = rgbsigma + r * K * 4;
+    float *dr = d_rgbsigma + r * K * 4;
+    const float gr = d_rgb[r * 3 + 0], gg = d_rgb[r * 3 + 1], gb = d_rgb[r * 3 + 2], gd = d_depth ? d_depth[r] : 0.0f;
+    // dL/dw_k = g.c_k + gd z_k - white*(gr+gg+gb) + d_weights_k
+    // w_k = alpha_k T_k;  T_{k+1} = T_k (1 - alpha_k + eps)
+    // reverse sweep with S_k = sum_{j>k} dL/dw_j w_j  (dT_j/dalpha_k = -T_j/(1-alpha_k+eps) for j > k)
+    // forward sweep: park T_k in the sigma slot of the output (overwritten by the reverse sweep); recomputing
+    // T_k backwards by division would lose it once the transmittance underflows behind an opaque sample
+    float T = 1.0f;
+    for (int k = 0; k < K; ++k) {
+        const float delta = (k + 1 < K) ? zr[k + 1] - zr[k] : far - zr[k];
+        const float sg = cr[k * 4 + 3] > 0.0f ? cr[k * 4 + 3] : 0.0f;
+        dr[k * 4 + 3] = T;
+        T = T * (1.0f - (1.0f - expf(-delta * sg)) + 1e-10f);
+    }
+    float S = 0.0f;  // sum_{j>k} dLdw_j * w_j
+    const float gwhite = white_bkgd ? (gr + gg + gb) : 0.0f;
+    for (int k = K - 1; k >= 0; --k) {
+        const float delta = (k + 1 < K) ? zr[k + 1] - zr[k] : far - zr[k];
+        const float sraw = cr[k * 4 + 3], sg = sraw > 0.0f ? sraw : 0.0f;
+        const float e = expf(-delta * sg), alpha = 1.0f - e, keep = 1.0f - alpha + 1e-10f;
+        const float Tk = dr[k * 4 + 3];
+        const float w = alpha * Tk;
+        const float dLdw = gr * cr[k * 4 + 0] + gg * cr[k * 4 + 1] + gb * cr[k * 4 + 2] + gd * zr[k] - gwhite + (d_weights ? d_weights[r * K + k] : 0.0f);
+        dr[k * 4 + 0] = gr * w; dr[k * 4 + 1] = gg * w; dr[k * 4 + 2] = gb * w;
+        const float dLdalpha = dLdw * Tk - S / keep;
+        // alpha = 1 - exp(-delta * relu(sigma)) -> d alpha / d sigma = delta * e  (0 where sigma <= 0)
+        dr[k * 4 + 3] = sraw > 0.0f ? dLdalpha * delta * e : 0.0f;
+        S += dLdw * w;
+    }
+}
+
+}  // namespace train
+
+using namespace train;
+
+int launch_train_gemm(const float *A, const float *B, const float *bias, const float *S, float *C, int64_t M, int N, int K,
+                      int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc, int64_t lds, int relu_a, int relu_b,
+                      int accumulate, int atomic, int64_t k_chunk, hipStream_t st)
+{
+    GemmArgs g{A, B, bias, S, C, M, N, K, sam, sak, sbk, sbn, ldc, lds, relu_a, relu_b, accumulate, atomic, k_chunk};
+    return launch_gemm(g, st);
+}
+
+int launch_train_colsum(const float *dY, int64_t M, int N, int64_t ld, float *db, hipStream_t st)
+{
+    if (M == 0 || N == 0) return DINER_OK;
+    const unsigned chunks = (unsigned)(M / 4096 + 1);
+    hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)((N + 63) / 64), chunks > 512 ? 512 : chunks), dim3(256), 0, st, dY, M, N, ld, db);
+    return check_launch("train::colsum_kernel");
+}
+
+int launch_train_point_inputs(const DinerScene &s, const float *latent_nchw, const float *rays, const float *z, int64_t NR, int K,
+                              int sb, float *in56, float *zlat, float *taps, hipStream_t st)
+{
+    const int64_t R = NR * (int64_t)K * s.NV;
+    if (R == 0) return DINER_OK;
+    hipLaunchKernelGGL(point_inputs_kernel, dim3((unsigned)R), dim3(64), 0, st, s, latent_nchw, rays, z, NR, K, sb, in56, zlat, taps);
+    return check_launch("train::point_inputs_kernel");
+}
+
+int launch_train_bilinear_scatter(const float *dz, const float *taps, int64_t P, int C, int h, int w, int NV, int sb,
+                                  float *dlatent, hipStream_t st)
+{
+    if (P * NV == 0) return DINER_OK;
+    hipLaunchKernelGGL(bilinear_scatter_kernel, dim3((unsigned)(P * NV)), dim3(64), 0, st, dz, taps, P, C, h, w, NV, sb, dlatent);
+    return check_launch("train::bilinear_scatter_kernel");
+}
+
+int launch_train_view_mean(const float *x, int64_t PC, int NV, float *xbar, int backward, hipStream_t st)
+{
+    if (PC == 0) return DINER_OK;
+    const dim3 grid((unsigned)((PC + 255) / 256));
+    if (backward) hipLaunchKernelGGL(view_mean_bwd_kernel, grid, dim3(256), 0, st, x, PC, NV, xbar);
+    else hipLaunchKernelGGL(view_mean_kernel, grid, dim3(256), 0, st, x, PC, NV, xbar);
+    return check_launch("train::view_mean_kernel");
+}
+
+int launch_train_head(const float *out, const float *rgbsigma, const float *d_rgbsigma, int64_t n4, float *result, int backward,
+                      hipStream_t st)
+{
+    if (n4 == 0) return DINER_OK;
+    const dim3 grid((unsigned)((n4 + 255) / 256));
+    if (backward) hipLaunchKernelGGL(head_bwd_kernel, grid, dim3(256), 0, st, out, rgbsigma, d_rgbsigma, n4, result);
+    else hipLaunchKernelGGL(head_kernel, grid, dim3(256), 0, st, out, n4, result);
+    return check_launch("train::head_kernel");
+}
+
+int launch_train_composite_bwd(const float *rays, const float *z, const float *rgbsigma, const float *d_rgb, const float *d_depth,
+                               const float *d_weights, int64_t N, int K, int white_bkgd, float *d_rgbsigma, hipStream_t st)
+{
+    if (N == 0) return DINER_OK;
+    hipLaunchKernelGGL(composite_bwd_kernel, dim3((unsigned)((N + 63) / 64)), dim3(64), 0, st, rays, z, rgbsigma, d_rgb, d_depth,
+                       d_weights, N, K, white_bkgd, d_rgbsigma);
+    return check_launch("train::composite_bwd_kernel");
+}
+
+}  // namespace diner

@@ -328,7 +328,8 @@ class NeRFRendererDGS(torch.nn.Module):
         """
         assert len(rays.shape) == 3
         self._validate_model(model)
-        self._require_no_grad(model)
+        if torch.is_grad_enabled() and (any(p.requires_grad for p in model.mlp_fine.parameters()) or model.encoder.latent.requires_grad):
+            return self._forward_train(model, rays, want_weights, noise=noise, z_samples=z_samples)
         with torch.no_grad():
             r = self._check_rays(rays)
             SB, NR, _ = r.shape
@@ -370,6 +371,27 @@ class NeRFRendererDGS(torch.nn.Module):
                                             _ptr(depth), _ptr(weights), st), "diner_composite")
                     ev[3].record()
                     self.stage_events.append(ev)
+        return RenderOutput(fine=self._format_outputs(weights, rgb, depth, want_weights=want_weights))
+
+    def _forward_train(self, model, rays, want_weights, noise=None, z_samples=None):
+        """Training path (reference DINER.calc_losses, src/models/diner.py:217-290): sampler under no_grad
+        (src/models/nerf_renderer.py:65), then the differentiable point evaluation + compositing of
+        diner_amd/training.py (HIP building blocks; gradients to the MLP parameters and encoder.latent)."""
+        from . import training
+        r = self._check_rays(rays)
+        SB, NR, _ = r.shape
+        K = int(self.n_samples)
+        with torch.no_grad():
+            if z_samples is not None:
+                z = _f32c(z_samples)
+            else:
+                z = self._sample(r, model, K, self.n_depth_candidates, self.n_gaussian, 0.05, noise, None)["z"]
+            sc, _keep = self._scene(model, need_latent=False)
+        assert SB == sc.SB
+        lat = model.encoder.latent
+        assert lat.shape[:2] == (sc.SB, sc.NV) and lat.shape[2] == 512
+        sc.C, sc.h, sc.w = int(lat.shape[2]), int(lat.shape[3]), int(lat.shape[4])
+        rgb, depth, weights = training.render_with_grad(self, model, r, z, sc)
         return RenderOutput(fine=self._format_outputs(weights, rgb, depth, want_weights=want_weights))
 
     # alias asked for by the north_star text; the reference itself has no render_rays

@@ -174,6 +174,37 @@ int diner_render(const DinerScene *scene, const float *mlp_packed, const float *
                  const float *n_gauss, const float *u_fill, uint64_t seed, float *workspace,
                  float *rgb_out, float *depth_out, float *weights_out, void *stream);
 
+/* ---- training path: building blocks of the forward-with-saved-activations and
+ * the backward of composite (src/models/nerf_renderer.py:286-365) + PixelNeRF.forward
+ * (src/models/pixelnerf.py:55-145) + ResnetFC.forward (src/models/resnetfc.py:129-159), orchestrated by
+ * diner_amd/training.py exactly like autograd orchestrates the reference's ATen ops.  Gradients: MLP
+ * parameters and encoder.latent (NCHW); the sampler is @torch.no_grad in the reference. ------------------ */
+/* C[m][n] (+)= sum_k opA(A[m*sam + k*sak]) * opB(B[k*sbk + n*sbn]) (+ bias[n]) (* [S[m*lds + n] > 0]);
+ * exact fp32 MFMA.  Each operand must be contiguous along one of its two indices; N % 4 == 0;
+ * k_chunk (0 = no split) splits the contraction over blockIdx.z (use with atomic = 1). */
+int diner_train_gemm(const float *A, const float *B, const float *bias, const float *S, float *C, int64_t M,
+                     int32_t N, int32_t K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc,
+                     int64_t lds, int32_t relu_a, int32_t relu_b, int32_t accumulate, int32_t atomic,
+                     int64_t k_chunk, void *stream);
+/* db[n] += sum_m dY[m*ld + n] */
+int diner_train_colsum(const float *dY, int64_t M, int32_t N, int64_t ld, float *db, void *stream);
+/* per (view, point) row = v*P + p of scene sb: in56 [R,56] (55 inputs of pixelnerf.py:128 + 0), z [R,512]
+ * (bilinear latent, image_encoder.py:97-127) from the NCHW latent, taps [R,8] (4 texel indices, 4 weights) */
+int diner_train_point_inputs(const DinerScene *scene, const float *latent_nchw, const float *rays, const float *z,
+                             int64_t NR, int32_t K, int32_t sb, float *in56, float *zlat, float *taps, void *stream);
+/* dlatent[sb][v][ch][texel] += dz[row][ch] * weight (atomic) */
+int diner_train_bilinear_scatter(const float *dz, const float *taps, int64_t P, int32_t C, int32_t h, int32_t w,
+                                 int32_t NV, int32_t sb, float *dlatent_nchw, void *stream);
+/* forward: x [NV,PC] -> mean [PC] (resnetfc.py:146-149); backward: d_mean [PC] -> dx [NV,PC] */
+int diner_train_view_mean(const float *x, int64_t PC, int32_t NV, float *out, int32_t backward, void *stream);
+/* forward: out [n4] -> sigmoid/relu head (pixelnerf.py:139-143); backward: d_out from d_rgbsigma */
+int diner_train_head(const float *out, const float *rgbsigma, const float *d_rgbsigma, int64_t n4, float *result,
+                     int32_t backward, void *stream);
+/* backward of diner_composite: d_rgb [N,3], d_depth [N]|NULL, d_weights [N,K]|NULL -> d_rgbsigma [N,K,4] */
+int diner_composite_backward(const float *rays, const float *z, const float *rgbsigma, const float *d_rgb,
+                             const float *d_depth, const float *d_weights, int64_t N, int32_t K,
+                             int32_t white_bkgd, float *d_rgbsigma, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -96,12 +96,61 @@ def gen_glue(out_dir):
     print(f"glue: rays {rays.shape} normals {normals.shape} nan={np.isnan(normals).sum()}")
 
 
+TRAIN_CASE = dict(scene=dict(H=16, W=16, NV=2, seed=12, dataset="facescape", feature_padding=4), K=8, NC=64, G=3,
+                  ray_stride=8, focal_scale=1.0, wseed=13, bias_scale=0.1, nseed=14, cseed=15)
+
+
+def train_cotangents(NR, cseed):
+    rs = np.random.RandomState(cseed)
+    return rs.standard_normal((1, NR, 3)).astype(np.float32), rs.standard_normal((1, NR)).astype(np.float32)
+
+
+def grad_probe_indices(shape, n=64, seed=99):
+    rs = np.random.RandomState(seed + int(np.prod(shape)) % 1000)
+    return rs.randint(0, int(np.prod(shape)), size=min(n, int(np.prod(shape))))
+
+
+def gen_train(out_dir):
+    """Gradients of L = <c_rgb, rgb> + <c_depth, depth> w.r.t. every MLP parameter and the latent, from the
+    reference's own autograd (composite + PixelNeRF.forward + ResnetFC on the reference's sorted samples)."""
+    import torch
+    from oracle import ref_harness as rh
+    cfg = TRAIN_CASE
+    sc, w, rays, noise = case_inputs(cfg)
+    nerf = rh.build_model(sc, w)
+    ref = rh.run_reference(nerf, rays, cfg["K"], cfg["NC"], cfg["G"], noise, white_bkgd=sc.white_bkgd, want_internals=False)
+    z = torch.from_numpy(ref["z_fill"])
+    nerf.encoder.latent = nerf.encoder.latent.clone().requires_grad_(True)
+    for p in nerf.mlp_fine.parameters():
+        p.requires_grad_(True)
+    rend = rh.import_reference().NeRFRendererDGS(n_samples=cfg["K"], n_depth_candidates=cfg["NC"], n_gaussian=cfg["G"],
+                                                 white_bkgd=sc.white_bkgd)
+    weights, rgb, depth = rend.composite(nerf, torch.from_numpy(rays), z)
+    c_rgb, c_depth = train_cotangents(rays.shape[1], cfg["cseed"])
+    loss = (rgb * torch.from_numpy(c_rgb)).sum() + (depth * torch.from_numpy(c_depth)).sum()
+    loss.backward()
+    fixture = dict(config=json.dumps(cfg), z_fill=ref["z_fill"], rgb=rgb.detach().numpy(), depth=depth.detach().numpy(),
+                   latent_grad=nerf.encoder.latent.grad.numpy())
+    for name, p in nerf.mlp_fine.named_parameters():
+        gnp = p.grad.numpy()
+        idx = grad_probe_indices(gnp.shape)
+        fixture[f"g_sum/{name}"] = np.float64(gnp.astype(np.float64).sum())
+        fixture[f"g_norm/{name}"] = np.float64(np.sqrt((gnp.astype(np.float64) ** 2).sum()))
+        fixture[f"g_probe/{name}"] = gnp.reshape(-1)[idx]
+    np.savez_compressed(out_dir / "train.npz", **fixture)
+    print(f"train: NR={rays.shape[1]} |latent_grad|={np.abs(fixture['latent_grad']).max():.3e} "
+          f"|g lin_out.w|={fixture['g_norm/lin_out.weight']:.3e} |g lin_in.w|={fixture['g_norm/lin_in.weight']:.3e}")
+
+
 def main():
     from oracle import ref_harness as rh
     out_dir = ROOT / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
     gen_glue(out_dir)
     if "--glue-only" in sys.argv:
+        return
+    gen_train(out_dir)
+    if "--train-only" in sys.argv:
         return
     for name, cfg in CASES.items():
         t0 = time.time()
