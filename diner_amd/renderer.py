@@ -298,6 +298,10 @@ class NeRFRendererDGS(torch.nn.Module):
         r = self._check_rays(rays)
         z = _f32c(z_samp)
         SB, NR, K = z.shape
+        if rgbsigma is None and torch.is_grad_enabled() and (any(p.requires_grad for p in model.mlp_fine.parameters())
+                                                             or model.encoder.latent.requires_grad):
+            out = self._forward_train(model, rays, True, z_samples=z).fine   # differentiable like the reference's composite
+            return out.weights, out.rgb, out.depth
         if rgbsigma is None:
             rgbsigma = self.render_points(model, rays, z)
         c = _f32c(rgbsigma)
@@ -313,8 +317,8 @@ class NeRFRendererDGS(torch.nn.Module):
     def _require_no_grad(model):
         if torch.is_grad_enabled() and any(p.requires_grad for p in model.mlp_fine.parameters()):
             raise RuntimeError(
-                "diner_amd.NeRFRendererDGS is forward-only (the backward of composite/PixelNeRF.forward is the "
-                "next scope row, SURVEY.md §8(f)-1): call it under torch.no_grad() for evaluation.")
+                "render_points() is the fused inference kernel and carries no autograd graph: call forward()/composite() "
+                "(they switch to the differentiable training path of diner_amd/training.py) or wrap it in torch.no_grad().")
 
     # ------------------------------------------------------------------------------------------
     def forward(self, model, rays, want_weights=False, *, noise=None, z_samples=None):
