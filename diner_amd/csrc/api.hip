@@ -39,6 +39,7 @@ int launch_train_point_inputs(const DinerScene &, const float *, const float *, 
                               float *, hipStream_t);
 int launch_train_bilinear_scatter(const float *, const float *, int64_t, int, int, int, int, int, float *, hipStream_t);
 int launch_train_view_mean(const float *, int64_t, int, float *, int, hipStream_t);
+int launch_train_nhwc_to_nchw(const float *, int64_t, int, int, int, float *, hipStream_t);
 int launch_train_head(const float *, const float *, const float *, int64_t, float *, int, hipStream_t);
 int launch_train_composite_bwd(const float *, const float *, const float *, const float *, const float *, const float *, int64_t, int,
                                int, float *, hipStream_t);
@@ -238,10 +239,16 @@ int diner_train_point_inputs(const DinerScene *scene, const float *latent_nchw, 
 }
 
 int diner_train_bilinear_scatter(const float *dz, const float *taps, int64_t P, int32_t C, int32_t h, int32_t w, int32_t NV, int32_t sb,
-                                 float *dlatent_nchw, void *stream)
+                                 float *dlatent_nhwc, void *stream)
 {
-    if (!dz || !taps || !dlatent_nchw) return bad("train_bilinear_scatter: NULL pointer");
-    return launch_train_bilinear_scatter(dz, taps, P, C, h, w, NV, sb, dlatent_nchw, (hipStream_t)stream);
+    if (!dz || !taps || !dlatent_nhwc) return bad("train_bilinear_scatter: NULL pointer");
+    return launch_train_bilinear_scatter(dz, taps, P, C, h, w, NV, sb, dlatent_nhwc, (hipStream_t)stream);
+}
+
+int diner_train_nhwc_to_nchw(const float *nhwc, int64_t N, int32_t C, int32_t h, int32_t w, float *nchw_out, void *stream)
+{
+    if (!nhwc || !nchw_out || N < 0 || C <= 0 || h <= 0 || w <= 0) return bad("train_nhwc_to_nchw: bad argument");
+    return launch_train_nhwc_to_nchw(nhwc, N, C, h, w, nchw_out, (hipStream_t)stream);
 }
 
 int diner_train_view_mean(const float *x, int64_t PC, int32_t NV, float *out, int32_t backward, void *stream)

@@ -24,7 +24,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace train {
 
-constexpr int BM = 64, BN = 64, BK = 16, LDT = 68;  // LDS tile row stride (floats), 16-byte aligned rows
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132;  // block tile; LDS tile row stride (floats, 16-byte aligned rows)
 
 struct GemmArgs {
     const float *A, *B, *bias, *S;
@@ -37,70 +37,112 @@ struct GemmArgs {
     int64_t k_chunk;             // split-K: blockIdx.z handles k in [z*k_chunk, (z+1)*k_chunk)
 };
 
-// AK: A contiguous along k (sak == 1) else along m (sam == 1).  BN_: B contiguous along n (sbn == 1) else along k.
+// One operand tile (128 x 16, as [k][m]) = 512 float4, two per thread.  KC: the operand is contiguous along the
+// contraction index (float4 along k, transposed into the tile), else along the tile's long index.
+template <bool KC>
+__device__ __forceinline__ void tile_load(f32x4 (&v)[2], const float *__restrict__ base, int64_t s_long, int64_t s_k, int64_t l0,
+                                          int64_t l_end, int64_t k0, int64_t k_end, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (KC) {
+            const int l = idx >> 2, kq = (idx & 3) * 4;
+            if (l0 + l < l_end && k0 + kq < k_end) v[i] = *(const f32x4 *)(base + (l0 + l) * s_long + (k0 + kq));
+        } else {
+            const int k = idx >> 5, lq = (idx & 31) * 4;
+            if (k0 + k < k_end && l0 + lq < l_end) v[i] = *(const f32x4 *)(base + (k0 + k) * s_k + (l0 + lq));
+        }
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void tile_store(float (*T)[LDT], const f32x4 (&v)[2], int relu, int tid)
+{
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 256 * i;
+        f32x4 x = v[i];
+        if (relu) { for (int j = 0; j < 4; ++j) x[j] = x[j] > 0.f ? x[j] : 0.f; }
+        if (KC) {
+            const int l = idx >> 2, kq = (idx & 3) * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) T[kq + j][l] = x[j];
+        } else {
+            const int k = idx >> 5, lq = (idx & 31) * 4;
+            *(f32x4 *)&T[k][lq] = x;
+        }
+    }
+}
+
+// AK: A contiguous along k (sak == 1) else along m (sam == 1).  BNC: B contiguous along n (sbn == 1) else along k.
+// 4 waves as 2 x 2, each a 64 x 64 output (2 x 2 MFMA tiles); global loads of tile t+1 are in flight while tile t
+// is multiplied out of LDS (double-buffered, one barrier per k-step).
 template <bool AK, bool BNC>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
 {
-    __shared__ float As[BK][LDT], Bs[BK][LDT];
+    __shared__ float As[2][BK][LDT], Bs[2][BK][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t m0 = (int64_t)blockIdx.x * BM;
     const int n0 = blockIdx.y * BN;
     const int64_t kbeg = (int64_t)blockIdx.z * g.k_chunk;
     const int64_t kend = kbeg + g.k_chunk < g.K ? kbeg + g.k_chunk : g.K;
-    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
-    f32x16 acc;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    f32x16 acc[2][2];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0f;
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    f32x4 ra[2], rb[2];
+    tile_load<AK>(ra, g.A, g.sam, g.sak, m0, g.M, kbeg, kend, tid);
+    tile_load<!BNC>(rb, g.B, g.sbn, g.sbk, n0, g.N, kbeg, kend, tid);
+    tile_store<AK>(As[0], ra, g.relu_a, tid);
+    tile_store<!BNC>(Bs[0], rb, g.relu_b, tid);
+    __syncthreads();
+    int buf = 0;
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
-        // ---- stage A tile: As[k][m] ----
-        if (AK) {  // float4 along k: thread -> (m = tid/4, k quad = tid%4)
-            const int m = tid >> 2, kq = (tid & 3) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m0 + m < g.M && k0 + kq < kend) v = *(const f32x4 *)(g.A + (m0 + m) * g.sam + (k0 + kq));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) As[kq + i][m] = g.relu_a ? (v[i] > 0.f ? v[i] : 0.f) : v[i];
-        } else {   // float4 along m: thread -> (k = tid/16, m quad = tid%16)
-            const int k = tid >> 4, mq = (tid & 15) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k0 + k < kend && m0 + mq < g.M) v = *(const f32x4 *)(g.A + (k0 + k) * g.sak + (m0 + mq));
-            if (g.relu_a) { for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f; }
-            *(f32x4 *)&As[k][mq] = v;
+        const bool more = k0 + BK < kend;
+        if (more) {
+            tile_load<AK>(ra, g.A, g.sam, g.sak, m0, g.M, k0 + BK, kend, tid);
+            tile_load<!BNC>(rb, g.B, g.sbn, g.sbk, n0, g.N, k0 + BK, kend, tid);
         }
-        // ---- stage B tile: Bs[k][n] ----
-        if (BNC) {
-            const int k = tid >> 4, nq = (tid & 15) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (k0 + k < kend && n0 + nq < g.N) v = *(const f32x4 *)(g.B + (k0 + k) * g.sbk + (n0 + nq));
-            if (g.relu_b) { for (int i = 0; i < 4; ++i) v[i] = v[i] > 0.f ? v[i] : 0.f; }
-            *(f32x4 *)&Bs[k][nq] = v;
-        } else {
-            const int n = tid >> 2, kq = (tid & 3) * 4;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n0 + n < g.N && k0 + kq < kend) v = *(const f32x4 *)(g.B + (int64_t)(n0 + n) * g.sbn + (k0 + kq));
-#pragma unroll
-            for (int i = 0; i < 4; ++i) Bs[kq + i][n] = g.relu_b ? (v[i] > 0.f ? v[i] : 0.f) : v[i];
-        }
-        __syncthreads();
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const float a = As[kk + (lane >> 5)][wm + (lane & 31)], b = Bs[kk + (lane >> 5)][wn + (lane & 31)];
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            const int kr = kk + (lane >> 5), c = lane & 31;
+            const float a0 = As[buf][kr][wm + c], a1 = As[buf][kr][wm + 32 + c];
+            const float b0 = Bs[buf][kr][wn + c], b1 = Bs[buf][kr][wn + 32 + c];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (more) {
+            tile_store<AK>(As[buf ^ 1], ra, g.relu_a, tid);
+            tile_store<!BNC>(Bs[buf ^ 1], rb, g.relu_b, tid);
         }
         __syncthreads();
+        buf ^= 1;
     }
     // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5) ----
-    const int n = n0 + wn + (lane & 31);
-    if (n >= g.N) return;
-    const float bias = (g.bias && blockIdx.z == 0) ? g.bias[n] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int64_t m = m0 + wm + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-        if (m >= g.M) continue;
-        float v = acc[i] + bias;
-        if (g.S) v = g.S[m * g.lds_ + n] > 0.0f ? v : 0.0f;
-        float *c = g.C + m * g.ldc + n;
-        if (g.atomic) atomicAdd(c, v);
-        else *c = g.accumulate ? *c + v : v;
+    for (int tb = 0; tb < 2; ++tb) {
+        const int n = n0 + wn + tb * 32 + (lane & 31);
+        if (n >= g.N) continue;
+        const float bias = (g.bias && blockIdx.z == 0) ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t m = m0 + wm + ta * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
+                if (m >= g.M) continue;
+                float v = acc[ta][tb][i] + bias;
+                if (g.S) v = g.S[m * g.lds_ + n] > 0.0f ? v : 0.0f;
+                float *c = g.C + m * g.ldc + n;
+                if (g.atomic) atomicAdd(c, v);
+                else *c = g.accumulate ? *c + v : v;
+            }
     }
 }
 
@@ -197,15 +239,17 @@ __global__ __launch_bounds__(64) void point_inputs_kernel(DinerScene s, const fl
     }
 }
 
-// dlatent[v][ch][tap] += dz[row][ch] * w_tap  (bilinear backward; atomics: several points share a texel)
+// dlatent_nhwc[v][texel][ch] += dz[row][ch] * w_tap  (bilinear backward; atomics: several points share a texel).
+// The target is NHWC on purpose: a wave's 64 channels of one texel are 256 contiguous bytes, the shape in which
+// float atomics run at the full memory-side rate (64 lanes in 64 different rows are ~17x slower: scattering
+// straight into the reference's NCHW layout took 82 ms per step, this + the transpose below 5 ms).
 __global__ __launch_bounds__(64) void bilinear_scatter_kernel(const float *__restrict__ dz, const float *__restrict__ taps,
                                                               int64_t P, int C, int h, int w, int NV, int sb,
-                                                              float *__restrict__ dlatent_nchw)
+                                                              float *__restrict__ dlatent_nhwc)
 {
     const int64_t row = blockIdx.x;
     const int v = (int)(row / P), lane = threadIdx.x;
-    const int64_t plane = (int64_t)h * w;
-    float *lat = dlatent_nchw + ((int64_t)sb * NV + v) * C * plane;
+    float *lat = dlatent_nhwc + ((int64_t)sb * NV + v) * h * w * C;
     int o[4];
     float wt[4];
 #pragma unroll
@@ -214,8 +258,20 @@ __global__ __launch_bounds__(64) void bilinear_scatter_kernel(const float *__res
         const float g = dz[row * C + ch];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (wt[i] != 0.0f) atomicAdd(lat + ch * plane + o[i], g * wt[i]);
+            if (wt[i] != 0.0f) atomicAdd(lat + (int64_t)o[i] * C + ch, g * wt[i]);
     }
+}
+
+// [N,h*w,C] -> [N,C,h*w] (the layout of encoder.latent and of its gradient), tiled through LDS
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *__restrict__ in, int64_t hw, int C, float *__restrict__ out)
+{
+    __shared__ float tile[32][33];
+    const int64_t img = blockIdx.z, p0 = (int64_t)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8) tile[i][tx] = (p0 + i < hw && c0 + tx < C) ? in[(img * hw + p0 + i) * C + c0 + tx] : 0.f;
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < C && p0 + tx < hw) out[(img * C + c0 + i) * hw + p0 + tx] = tile[tx][i];
 }
 
 // mean over views (resnetfc.py:146-149): x [NV,P,C] -> xbar [P,C];  backward: dx[v] = dxbar / NV
@@ -331,6 +387,15 @@ int launch_train_bilinear_scatter(const float *dz, const float *taps, int64_t P,
     if (P * NV == 0) return DINER_OK;
     hipLaunchKernelGGL(bilinear_scatter_kernel, dim3((unsigned)(P * NV)), dim3(64), 0, st, dz, taps, P, C, h, w, NV, sb, dlatent);
     return check_launch("train::bilinear_scatter_kernel");
+}
+
+int launch_train_nhwc_to_nchw(const float *in, int64_t N, int C, int h, int w, float *out, hipStream_t st)
+{
+    const int64_t hw = (int64_t)h * w;
+    if (N * hw == 0) return DINER_OK;
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)((hw + 31) / 32), (unsigned)((C + 31) / 32), (unsigned)N), dim3(256), 0, st, in,
+                       hw, C, out);
+    return check_launch("train::nhwc_to_nchw_kernel");
 }
 
 int launch_train_view_mean(const float *x, int64_t PC, int NV, float *xbar, int backward, hipStream_t st)

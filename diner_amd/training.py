@@ -145,7 +145,8 @@ class _RenderFn(torch.autograd.Function):
                                          int(bool(ctx.renderer.white_bkgd)), _p(d_rgbsigma), st), "diner_composite_backward")
         g = [torch.zeros_like(p) for p in prm]          # parameter gradients (fp32, accumulated atomically)
         g_in56 = torch.zeros_like(ctx.w_in56)
-        d_lat = torch.zeros(ctx.lat_shape, dtype=torch.float32, device=dev)
+        SBl, NVl, Cl, hl, wl = ctx.lat_shape
+        d_lat_nhwc = torch.zeros((SBl, NVl, hl, wl, Cl), dtype=torch.float32, device=dev)
         for sb in range(SB):
             in56, zl, taps, xs, nets, xbars, pnets, xbar5, out = ctx.saved_acts[sb]
             d_out = f(P, 4)
@@ -175,8 +176,10 @@ class _RenderFn(torch.autograd.Function):
                 linear_bwd_x(d_xs, prm[2 + 2 * b], None, d_zl, accumulate=True)
                 d_xv = d_xs
             linear_bwd_w(d_xv, in56, g_in56, g[1])                                 # lin_in
-            check(L.diner_train_bilinear_scatter(_p(d_zl), _p(taps), P, HID, scene.h, scene.w, NV, sb, _p(d_lat), st),
+            check(L.diner_train_bilinear_scatter(_p(d_zl), _p(taps), P, HID, scene.h, scene.w, NV, sb, _p(d_lat_nhwc), st),
                   "diner_train_bilinear_scatter")
+        d_lat = torch.empty(ctx.lat_shape, dtype=torch.float32, device=dev)
+        check(L.diner_train_nhwc_to_nchw(_p(d_lat_nhwc), SBl * NVl, Cl, hl, wl, _p(d_lat), st), "diner_train_nhwc_to_nchw")
         g[0] = g_in56[:, :55].contiguous()
         return (None, None, None, None, d_lat) + tuple(g)
 

@@ -192,9 +192,12 @@ int diner_train_colsum(const float *dY, int64_t M, int32_t N, int64_t ld, float 
  * (bilinear latent, image_encoder.py:97-127) from the NCHW latent, taps [R,8] (4 texel indices, 4 weights) */
 int diner_train_point_inputs(const DinerScene *scene, const float *latent_nchw, const float *rays, const float *z,
                              int64_t NR, int32_t K, int32_t sb, float *in56, float *zlat, float *taps, void *stream);
-/* dlatent[sb][v][ch][texel] += dz[row][ch] * weight (atomic) */
+/* dlatent_nhwc[sb][v][texel][ch] += dz[row][ch] * weight (float atomics on 256-byte contiguous rows; the
+ * caller zeroes the [SB,NV,h,w,C] buffer), then diner_train_nhwc_to_nchw gives encoder.latent's layout */
 int diner_train_bilinear_scatter(const float *dz, const float *taps, int64_t P, int32_t C, int32_t h, int32_t w,
-                                 int32_t NV, int32_t sb, float *dlatent_nchw, void *stream);
+                                 int32_t NV, int32_t sb, float *dlatent_nhwc, void *stream);
+int diner_train_nhwc_to_nchw(const float *nhwc, int64_t N, int32_t C, int32_t h, int32_t w, float *nchw_out,
+                             void *stream);
 /* forward: x [NV,PC] -> mean [PC] (resnetfc.py:146-149); backward: d_mean [PC] -> dx [NV,PC] */
 int diner_train_view_mean(const float *x, int64_t PC, int32_t NV, float *out, int32_t backward, void *stream);
 /* forward: out [n4] -> sigmoid/relu head (pixelnerf.py:139-143); backward: d_out from d_rgbsigma */
