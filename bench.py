@@ -195,6 +195,22 @@ def main():
                                               "avg_ms": [t_samp, t_comp]}},
     }
 
+    # ---- the same frame with exact fp32 MFMA (v_mfma_f32_32x32x2_f32) for reference, N=1 only: the default
+    #      f16x3 mode is an fp32-grade emulation (parity tests hold both modes to the same bars), this shows what
+    #      the emulation buys and that nothing hides behind it
+    if rank == 0 and world == 1 and args.precision == "f16x3" and not args.no_cpu_baseline:
+        rend.precision = "fp32"
+        with torch.no_grad():
+            step()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step()
+            torch.cuda.synchronize()
+            t_fp32 = time.perf_counter() - t0
+        rend.precision = args.precision
+        result["exact_fp32_mfma"] = {"value": NR / t_fp32, "unit": "rays/s", "ms_per_step": t_fp32 * 1e3,
+                                     "frac_of_fp32_mfma_peak": f_launch / t_fp32 / 1e12 / PEAK_MFMA_TFLOPS["fp32"]}
+
     # ---- CPU baseline: the oracle (C port of the reference algorithm) on a bounded sample ---------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.oracle import Oracle
