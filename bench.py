@@ -60,6 +60,19 @@ def flops_per_ray(K, NV):
     return K * 2 * (NV * 2_387_456 + 1_050_624)
 
 
+def host_cores():
+    """CPU cores this process may really use: the affinity mask capped by the cgroup CPU quota (the GPU boxes
+    expose all 256 hardware threads but grant 16 CPUs)."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = Path("/sys/fs/cgroup/cpu.max").read_text().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def traffic_bytes(args):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
     (2*FETCH_SIZE + WRITE_SIZE in KiB -> bytes, the gfx950 correction of the microarch guide); PMC runs
@@ -79,7 +92,7 @@ def main():
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
     ap.add_argument("--rays-per-call", type=int, default=0, help="0 = whole frame in one launch (native mode); "
                     "4096 = the reference's ray_batch_size (src/models/diner.py:57)")
-    ap.add_argument("--cpu-sample-rays", type=int, default=512)
+    ap.add_argument("--cpu-sample-rays", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32"], help="arithmetic of the fusion-MLP GEMMs")
     args = ap.parse_args()
@@ -105,7 +118,7 @@ def main():
     h, w = scene.latent_hw
     gen = torch.Generator(device=dev).manual_seed(1234)
     latent = torch.randn((1, NV, 512, h, w), generator=gen, device=dev, dtype=torch.float32)
-    weights = synth.make_mlp_weights(1, bias_scale=0.1)
+    weights = synth.make_mlp_weights(7, bias_scale=0.1)  # seed with sigma > 0 almost everywhere: a meaningful parity sample
     model = model_from_scene(scene, weights, device=dev, latent=latent)
     rend = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G, white_bkgd=scene.white_bkgd)
     rend.precision = args.precision
@@ -214,7 +227,7 @@ def main():
     # ---- CPU baseline: the oracle (C port of the reference algorithm) on a bounded sample ---------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.oracle import Oracle
-        cores = len(os.sched_getaffinity(0))
+        cores = host_cores()
         n_s = min(args.cpu_sample_rays, NR)
         sel = np.linspace(0, NR - 1, n_s).astype(np.int64)
         rays_s = np.ascontiguousarray(rays.cpu().numpy()[:, sel])
