@@ -224,6 +224,26 @@ def main():
         result["exact_fp32_mfma"] = {"value": NR / t_fp32, "unit": "rays/s", "ms_per_step": t_fp32 * 1e3,
                                      "frac_of_fp32_mfma_peak": f_launch / t_fp32 / 1e12 / PEAK_MFMA_TFLOPS["fp32"]}
 
+    # ---- the same frame in the reference's call granularity (ray_batch_size 4096, src/models/diner.py:57): SURVEY.md
+    #      §8(d) asks for both the whole-frame launch (`value`) and this one
+    if rank == 0 and world == 1 and len(chunks) == 1 and NR > 4096 and not args.no_cpu_baseline:
+        small = list(torch.split(rays, 4096, dim=1))
+        with torch.no_grad():
+            for ch in small[:4]:
+                rend(model, ch)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            o = 0
+            for ch in small:
+                out = rend(model, ch)
+                n = ch.shape[1]
+                tile[o:o + n, :3] = out.fine.rgb[0]
+                tile[o:o + n, 3] = out.fine.depth[0]
+                o += n
+            torch.cuda.synchronize()
+            t_small = time.perf_counter() - t0
+        result["rays_per_call_4096"] = {"value": NR / t_small, "unit": "rays/s", "ms_per_frame": t_small * 1e3, "calls": len(small)}
+
     # ---- CPU baseline: the oracle (C port of the reference algorithm) on a bounded sample ---------
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle.oracle import Oracle
