@@ -33,7 +33,9 @@ int launch_pack_latent(const float *, int64_t, int, int, int, float *, hipStream
 int launch_pack_mlp(const DinerMlpRaw &, float *, hipStream_t);
 int64_t mlp_packed_floats();
 int launch_train_gemm(const float *, const float *, const float *, const float *, float *, int64_t, int, int, int64_t, int64_t, int64_t,
-                      int64_t, int64_t, int64_t, int, int, int, int, int64_t, hipStream_t);
+                      int64_t, int64_t, int64_t, int, int, int, int, int64_t, int, const unsigned int *, const unsigned int *, int, int,
+                      hipStream_t);
+int launch_train_amax(const float *, int64_t, unsigned int *, hipStream_t);
 int launch_train_colsum(const float *, int64_t, int, int64_t, float *, hipStream_t);
 int launch_train_point_inputs(const DinerScene &, const float *, const float *, const float *, int64_t, int, int, float *, float *,
                               float *, hipStream_t);
@@ -214,12 +216,21 @@ int diner_composite(const float *rays, const float *z, const float *rgbsigma, in
 /* ---- training path building blocks (train.hip) ------------------------------------------------ */
 int diner_train_gemm(const float *A, const float *B, const float *bias, const float *S, float *C, int64_t M, int32_t N, int32_t K,
                      int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc, int64_t lds, int32_t relu_a, int32_t relu_b,
-                     int32_t accumulate, int32_t atomic, int64_t k_chunk, void *stream)
+                     int32_t accumulate, int32_t atomic, int64_t k_chunk, int32_t precision, const void *amax_a, const void *amax_b,
+                     int32_t exp_a, int32_t exp_b, void *stream)
 {
     if (!A || !B || !C) return bad("train_gemm: NULL pointer");
-    if (M < 0 || N <= 0 || K <= 0 || (N & 3) || (k_chunk & 15)) return bad("train_gemm: bad size (N % 4, k_chunk % 16 must be 0)");
+    if (precision != DINER_PRECISION_FP32 && precision != DINER_PRECISION_F16X3) return bad("train_gemm: unknown precision");
+    if (M < 0 || N <= 0 || K <= 0 || (N & 3) || (k_chunk & 31)) return bad("train_gemm: bad size (N % 4, k_chunk % 32 must be 0)");
+    if (exp_a < -60 || exp_a > 60 || exp_b < -60 || exp_b > 60) return bad("train_gemm: scale exponent out of range");
     return launch_train_gemm(A, B, bias, S, C, M, N, K, sam, sak, sbk, sbn, ldc, lds, relu_a, relu_b, accumulate, atomic, k_chunk,
-                             (hipStream_t)stream);
+                             precision, (const unsigned int *)amax_a, (const unsigned int *)amax_b, exp_a, exp_b, (hipStream_t)stream);
+}
+
+int diner_train_amax(const float *x, int64_t n, void *amax_out, void *stream)
+{
+    if (!x || !amax_out || n < 0) return bad("train_amax: bad argument");
+    return launch_train_amax(x, n, (unsigned int *)amax_out, (hipStream_t)stream);
 }
 
 int diner_train_colsum(const float *dY, int64_t M, int32_t N, int64_t ld, float *db, void *stream)

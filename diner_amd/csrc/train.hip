@@ -35,35 +35,48 @@ struct GemmArgs {
     int64_t ldc, lds_;           // row strides of C and of the mask S
     int relu_a, relu_b, accumulate, atomic;
     int64_t k_chunk;             // split-K: blockIdx.z handles k in [z*k_chunk, (z+1)*k_chunk)
+    // f16x3 kernel only: operands are multiplied by a power of two before the fp16 hi/lo split (C is divided by
+    // the product): 2^exp_a / 2^exp_b, or -- when amax_a / amax_b point at a device word holding the bit pattern
+    // of max|operand| (diner_train_amax) -- the power of two that maps that maximum into [2^13, 2^14)
+    const unsigned int *amax_a, *amax_b;
+    int exp_a, exp_b;
 };
 
 // One operand tile (128 x 16, as [k][m]) = 512 float4, two per thread.  KC: the operand is contiguous along the
 // contraction index (float4 along k, transposed into the tile), else along the tile's long index.
+// Loads are unconditional (out-of-range pieces read a clamped in-range address and are zeroed by `ok` when the
+// tile is stored): a load under a branch makes hipcc wait for each one separately.
 template <bool KC>
-__device__ __forceinline__ void tile_load(f32x4 (&v)[2], const float *__restrict__ base, int64_t s_long, int64_t s_k, int64_t l0,
-                                          int64_t l_end, int64_t k0, int64_t k_end, int tid)
+__device__ __forceinline__ unsigned tile_load(f32x4 (&v)[2], const float *__restrict__ base, int64_t s_long, int64_t s_k, int64_t l0,
+                                              int64_t l_end, int64_t k0, int64_t k_end, int tid)
 {
+    unsigned ok = 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + 256 * i;
-        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (KC) {
-            const int l = idx >> 2, kq = (idx & 3) * 4;
-            if (l0 + l < l_end && k0 + kq < k_end) v[i] = *(const f32x4 *)(base + (l0 + l) * s_long + (k0 + kq));
+            const int64_t l = l0 + (idx >> 2), k = k0 + (idx & 3) * 4;
+            const bool in = l < l_end && k < k_end;
+            ok |= (unsigned)in << i;
+            v[i] = *(const f32x4 *)(base + (l < l_end ? l : l_end - 1) * s_long + (k < k_end ? k : k_end - 4));
         } else {
-            const int k = idx >> 5, lq = (idx & 31) * 4;
-            if (k0 + k < k_end && l0 + lq < l_end) v[i] = *(const f32x4 *)(base + (k0 + k) * s_k + (l0 + lq));
+            const int64_t k = k0 + (idx >> 5), l = l0 + (idx & 31) * 4;
+            const bool in = k < k_end && l < l_end;
+            ok |= (unsigned)in << i;
+            v[i] = *(const f32x4 *)(base + (k < k_end ? k : k_end - 1) * s_k + (l < l_end ? l : l_end - 4));
         }
     }
+    return ok;
 }
 template <bool KC>
-__device__ __forceinline__ void tile_store(float (*T)[LDT], const f32x4 (&v)[2], int relu, int tid)
+__device__ __forceinline__ void tile_store(float (*T)[LDT], const f32x4 (&v)[2], unsigned ok, int relu, int tid)
 {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + 256 * i;
         f32x4 x = v[i];
-        if (relu) { for (int j = 0; j < 4; ++j) x[j] = x[j] > 0.f ? x[j] : 0.f; }
+        const float lo = relu ? 0.f : -__builtin_inff();
+        for (int j = 0; j < 4; ++j) x[j] = ((ok >> i) & 1u) ? fmaxf(x[j], lo) : 0.f;
         if (KC) {
             const int l = idx >> 2, kq = (idx & 3) * 4;
 #pragma unroll
@@ -71,6 +84,66 @@ __device__ __forceinline__ void tile_store(float (*T)[LDT], const f32x4 (&v)[2],
         } else {
             const int k = idx >> 5, lq = (idx & 31) * 4;
             *(f32x4 *)&T[k][lq] = x;
+        }
+    }
+}
+
+// Block -> output tile.  Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2: the
+// column blocks of one 128-row tile (they all read the same A tile, the big streamed operand) are given to
+// consecutive workgroups of ONE XCD, so A leaves HBM once instead of once per column block.
+__device__ __forceinline__ void tile_of(const GemmArgs &g, int64_t &m0, int &n0)
+{
+    const int64_t gm = (g.M + BM - 1) / BM, lin = blockIdx.x;
+    const int gn = (g.N + BN - 1) / BN;
+    const int64_t full = gm / 8 * 8;
+    int64_t mt, nb;
+    if (lin < full * gn) { const int64_t j = lin / 8; nb = j % gn; mt = j / gn * 8 + lin % 8; }
+    else { const int64_t r = lin - full * gn; mt = full + r / gn; nb = r % gn; }
+    m0 = mt * BM;
+    n0 = (int)nb * BN;
+}
+
+// C layout of the 32x32 MFMA accumulators: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+__device__ __forceinline__ void epilogue(const GemmArgs &g, const f32x16 (&acc)[2][2], int64_t m0, int n0, int wm, int wn, int lane,
+                                         float unscale)
+{
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int n = n0 + wn + tb * 32 + (lane & 31);
+        if (n >= g.N) continue;
+        const float bias = (g.bias && blockIdx.z == 0) ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta) {
+            // all 16 reads of the tile (old C, mask) are issued before the first dependent store: one memory
+            // round trip per tile instead of one per element
+            const int64_t mb = m0 + wm + ta * 32 + 4 * (lane >> 5);
+            float old[16], msk[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { old[i] = 0.0f; msk[i] = 1.0f; }
+            if (g.accumulate && !g.atomic) {  // uniform branches, unconditional loads from clamped rows
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t m = mb + (i & 3) + 8 * (i >> 2);
+                    old[i] = g.C[(m < g.M ? m : g.M - 1) * g.ldc + n];
+                }
+            }
+            if (g.S) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t m = mb + (i & 3) + 8 * (i >> 2);
+                    msk[i] = g.S[(m < g.M ? m : g.M - 1) * g.lds_ + n];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t m = mb + (i & 3) + 8 * (i >> 2);
+                if (m >= g.M) continue;
+                float v = acc[ta][tb][i] * unscale + bias;
+                v = msk[i] > 0.0f ? v : 0.0f;
+                float *c = g.C + m * g.ldc + n;
+                if (g.atomic) atomicAdd(c, v);
+                else *c = old[i] + v;
+            }
         }
     }
 }
@@ -83,8 +156,9 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
 {
     __shared__ float As[2][BK][LDT], Bs[2][BK][LDT];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int64_t m0 = (int64_t)blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    int64_t m0;
+    int n0;
+    tile_of(g, m0, n0);
     const int64_t kbeg = (int64_t)blockIdx.z * g.k_chunk;
     const int64_t kend = kbeg + g.k_chunk < g.K ? kbeg + g.k_chunk : g.K;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
@@ -96,17 +170,17 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
     f32x4 ra[2], rb[2];
-    tile_load<AK>(ra, g.A, g.sam, g.sak, m0, g.M, kbeg, kend, tid);
-    tile_load<!BNC>(rb, g.B, g.sbn, g.sbk, n0, g.N, kbeg, kend, tid);
-    tile_store<AK>(As[0], ra, g.relu_a, tid);
-    tile_store<!BNC>(Bs[0], rb, g.relu_b, tid);
+    unsigned oka = tile_load<AK>(ra, g.A, g.sam, g.sak, m0, g.M, kbeg, kend, tid);
+    unsigned okb = tile_load<!BNC>(rb, g.B, g.sbn, g.sbk, n0, g.N, kbeg, kend, tid);
+    tile_store<AK>(As[0], ra, oka, g.relu_a, tid);
+    tile_store<!BNC>(Bs[0], rb, okb, g.relu_b, tid);
     __syncthreads();
     int buf = 0;
     for (int64_t k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = k0 + BK < kend;
         if (more) {
-            tile_load<AK>(ra, g.A, g.sam, g.sak, m0, g.M, k0 + BK, kend, tid);
-            tile_load<!BNC>(rb, g.B, g.sbn, g.sbk, n0, g.N, k0 + BK, kend, tid);
+            oka = tile_load<AK>(ra, g.A, g.sam, g.sak, m0, g.M, k0 + BK, kend, tid);
+            okb = tile_load<!BNC>(rb, g.B, g.sbn, g.sbk, n0, g.N, k0 + BK, kend, tid);
         }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
@@ -119,43 +193,209 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmArgs g)
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
         if (more) {
-            tile_store<AK>(As[buf ^ 1], ra, g.relu_a, tid);
-            tile_store<!BNC>(Bs[buf ^ 1], rb, g.relu_b, tid);
+            tile_store<AK>(As[buf ^ 1], ra, oka, g.relu_a, tid);
+            tile_store<!BNC>(Bs[buf ^ 1], rb, okb, g.relu_b, tid);
         }
         __syncthreads();
         buf ^= 1;
     }
-    // ---- epilogue: C layout of the 32x32 MFMA: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5) ----
+    epilogue(g, acc, m0, n0, wm, wn, lane, 1.0f);
+}
+
+// ---- the same GEMM with fp32-grade fp16 arithmetic (precision "f16x3", the renderer's default) --------------------
+// Every operand element is scaled by a power of two, split into fp16 hi + lo while it is staged into LDS, and each
+// product is three v_mfma_f32_32x32x16_f16 (lo*hi, hi*lo, hi*hi) with fp32 accumulation -- the arithmetic of
+// points_mlp_f16.hip.  128 x 128 x 32 block tiles, 4 waves as 2 x 2 (64 x 64 each), LDS images double-buffered.
+// An image holds 16-byte units (u = k/8, row) at u*128 + (row ^ 4u): an MFMA fragment (8 consecutive k of one
+// row) is one conflict-free ds_read_b128.
+namespace f16g {
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+constexpr int BKH = 32, UNITS_T = (BKH / 8) * 128;
+
+__device__ __forceinline__ int unit(int u, int row) { return u * 128 + (row ^ (4 * u)); }
+
+__device__ __forceinline__ void scale_of(const unsigned int *amax, int static_exp, float &s, float &inv)
+{
+    int e = static_exp;
+    if (amax) {
+        const unsigned int b = *amax;
+        const int ex = (int)((b >> 23) & 0xffu) - 127;
+        e = (b == 0u) ? 0 : 13 - ex;
+    }
+    e = e < -100 ? -100 : e > 100 ? 100 : e;
+    s = __uint_as_float((unsigned int)(127 + e) << 23);
+    inv = __uint_as_float((unsigned int)(127 - e) << 23);
+}
+
+// One operand tile = 128 (long index l) x 32 (k) fp32 = 1024 float4, four per thread.
+// KC (contiguous along k): float4 along k.  else: a 4(k) x 4(l) micro-tile per thread, float4 along l.
+template <bool KC>
+__device__ __forceinline__ unsigned tile_load(f32x4 (&v)[4], const float *__restrict__ base, int64_t s_long, int64_t s_k, int64_t l0,
+                                              int64_t l_end, int64_t k0, int64_t k_end, int tid)
+{
+    unsigned ok = 0;  // unconditional loads from clamped addresses + a validity bit per piece (see train::tile_load)
 #pragma unroll
-    for (int tb = 0; tb < 2; ++tb) {
-        const int n = n0 + wn + tb * 32 + (lane & 31);
-        if (n >= g.N) continue;
-        const float bias = (g.bias && blockIdx.z == 0) ? g.bias[n] : 0.0f;
+    for (int i = 0; i < 4; ++i) {
+        if (KC) {
+            const int idx = tid + 256 * i;
+            const int64_t l = l0 + (idx >> 3), k = k0 + (idx & 7) * 4;
+            ok |= (unsigned)(l < l_end && k < k_end) << i;
+            v[i] = *(const f32x4 *)(base + (l < l_end ? l : l_end - 1) * s_long + (k < k_end ? k : k_end - 4));
+        } else {
+            const int64_t k = k0 + (tid & 7) * 4 + i, l = l0 + (tid >> 3) * 4;
+            ok |= (unsigned)(k < k_end && l < l_end) << i;
+            v[i] = *(const f32x4 *)(base + (k < k_end ? k : k_end - 1) * s_k + (l < l_end ? l : l_end - 4));
+        }
+    }
+    return ok;
+}
+
+__device__ __forceinline__ void put4(h8 *Thi, h8 *Tlo, int l, int kq, float x0, float x1, float x2, float x3, float floor_, float sc)
+{
+    const float x[4] = {x0, x1, x2, x3};
+    h4 hi, lo;
 #pragma unroll
-        for (int ta = 0; ta < 2; ++ta)
+    for (int j = 0; j < 4; ++j) {
+        const float t = fmaxf(x[j] * sc, floor_);  // floor_ = 0 applies the relu, -inf does nothing
+        hi[j] = (_Float16)t;
+        lo[j] = (_Float16)(t - (float)hi[j]);
+    }
+    const int o = unit(kq >> 3, l) * 8 + (kq & 4);
+    *(h4 *)((_Float16 *)Thi + o) = hi;
+    *(h4 *)((_Float16 *)Tlo + o) = lo;
+}
+
+template <bool KC>
+__device__ __forceinline__ void tile_store(h8 *Thi, h8 *Tlo, const f32x4 (&v)[4], unsigned ok, float floor_, float sc, int tid)
+{
+    f32x4 x[4];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int64_t m = m0 + wm + ta * 32 + (i & 3) + 8 * (i >> 2) + 4 * (lane >> 5);
-                if (m >= g.M) continue;
-                float v = acc[ta][tb][i] + bias;
-                if (g.S) v = g.S[m * g.lds_ + n] > 0.0f ? v : 0.0f;
-                float *c = g.C + m * g.ldc + n;
-                if (g.atomic) atomicAdd(c, v);
-                else *c = g.accumulate ? *c + v : v;
-            }
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[i][j] = ((ok >> i) & 1u) ? v[i][j] : 0.0f;
+    if (KC) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            put4(Thi, Tlo, idx >> 3, (idx & 7) * 4, x[i][0], x[i][1], x[i][2], x[i][3], floor_, sc);
+        }
+    } else {
+        const int kq = (tid & 7) * 4, lq = (tid >> 3) * 4;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) put4(Thi, Tlo, lq + c, kq, x[0][c], x[1][c], x[2][c], x[3][c], floor_, sc);
     }
 }
 
-int launch_gemm(const GemmArgs &g, hipStream_t st)
+// The k-loop is a 3-stage pipeline: while tile t is multiplied out of LDS buffer t&1, tile t+1 sits in registers
+// (its loads were issued one step earlier and are split/stored into the other LDS buffer after the MFMAs) and the
+// loads of tile t+2 are issued.  One step of lead is not enough: the A operand streams from HBM (~2 us) and a
+// step is ~0.5 us of MFMA -- with a single stage in flight the kernel ran at 1.1 TB/s, latency-bound.
+template <bool AK, bool BNC>
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs g)
+{
+    __shared__ h8 T[2][4][UNITS_T];  // [buffer][A hi, A lo, B hi, B lo][unit]  (64 KiB)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int64_t m0;
+    int n0;
+    tile_of(g, m0, n0);
+    const int64_t kbeg = (int64_t)blockIdx.z * g.k_chunk;
+    const int64_t kend = kbeg + g.k_chunk < g.K ? kbeg + g.k_chunk : g.K;
+    const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+    float sa, ia, sb, ib;
+    scale_of(g.amax_a, g.exp_a, sa, ia);
+    scale_of(g.amax_b, g.exp_b, sb, ib);
+    const float fa = g.relu_a ? 0.0f : -__builtin_inff(), fb = g.relu_b ? 0.0f : -__builtin_inff();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    f32x4 ra[2][4], rb[2][4];
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t steps = (kend - kbeg + BKH - 1) / BKH;
+    unsigned oka[2], okb[2];
+    oka[0] = tile_load<AK>(ra[0], g.A, g.sam, g.sak, m0, g.M, kbeg, kend, tid);
+    okb[0] = tile_load<!BNC>(rb[0], g.B, g.sbn, g.sbk, n0, g.N, kbeg, kend, tid);
+    oka[1] = tile_load<AK>(ra[1], g.A, g.sam, g.sak, m0, g.M, kbeg + BKH, kend, tid);      // all-invalid past kend
+    okb[1] = tile_load<!BNC>(rb[1], g.B, g.sbn, g.sbk, n0, g.N, kbeg + BKH, kend, tid);
+    tile_store<AK>(T[0][0], T[0][1], ra[0], oka[0], fa, sa, tid);
+    tile_store<!BNC>(T[0][2], T[0][3], rb[0], okb[0], fb, sb, tid);
+    __syncthreads();
+#define DINER_GEMM_STEP(SL)                                                                                      \
+    {                                                                                                            \
+        const int64_t k2 = kbeg + (t + 2) * BKH;                                                                 \
+        if (t + 2 < steps) {                                                                                     \
+            oka[SL] = tile_load<AK>(ra[SL], g.A, g.sam, g.sak, m0, g.M, k2, kend, tid);                          \
+            okb[SL] = tile_load<!BNC>(rb[SL], g.B, g.sbn, g.sbk, n0, g.N, k2, kend, tid);                        \
+        }                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        _Pragma("unroll") for (int ks = 0; ks < BKH / 16; ++ks) {                                                \
+            const int u = ks * 2 + h;                                                                            \
+            h8 ah[2], al[2], bh[2], bl[2];                                                                       \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+                const int oa = unit(u, wm + 32 * q + r), ob = unit(u, wn + 32 * q + r);                          \
+                ah[q] = T[SL][0][oa]; al[q] = T[SL][1][oa];                                                      \
+                bh[q] = T[SL][2][ob]; bl[q] = T[SL][3][ob];                                                      \
+            }                                                                                                    \
+            _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                                     \
+                _Pragma("unroll") for (int tb = 0; tb < 2; ++tb) {                                               \
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ta], bh[tb], acc[ta][tb], 0, 0, 0);  \
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ta], bl[tb], acc[ta][tb], 0, 0, 0);  \
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ta], bh[tb], acc[ta][tb], 0, 0, 0);  \
+                }                                                                                                \
+        }                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        if (t + 1 < steps) {                                                                                     \
+            tile_store<AK>(T[1 - SL][0], T[1 - SL][1], ra[1 - SL], oka[1 - SL], fa, sa, tid);                    \
+            tile_store<!BNC>(T[1 - SL][2], T[1 - SL][3], rb[1 - SL], okb[1 - SL], fb, sb, tid);                  \
+        }                                                                                                        \
+        __syncthreads();                                                                                         \
+    }
+    for (int64_t t = 0; t < steps; ++t) {
+        DINER_GEMM_STEP(0)
+        if (++t >= steps) break;
+        DINER_GEMM_STEP(1)
+    }
+#undef DINER_GEMM_STEP
+    epilogue(g, acc, m0, n0, wm, wn, lane, ia * ib);
+}
+
+// max |x| over n floats as a bit pattern (non-negative floats order like unsigned integers); *out zeroed by the launcher
+__global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, int64_t n, unsigned int *__restrict__ out)
+{
+    float m = 0.f;
+    const int64_t n4 = n >> 2, stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        const f32x4 v = ((const f32x4 *)x)[i];
+        m = fmaxf(fmaxf(fmaxf(m, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) m = fmaxf(m, fabsf(x[(n4 << 2) + threadIdx.x]));
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
+}
+}  // namespace f16g
+
+int launch_gemm(const GemmArgs &g, int precision, hipStream_t st)
 {
     if (g.M == 0 || g.N == 0) return DINER_OK;
     const int64_t kc = g.k_chunk > 0 ? g.k_chunk : g.K;
     GemmArgs a = g;
     a.k_chunk = kc;
-    const dim3 grid((unsigned)((g.M + BM - 1) / BM), (unsigned)((g.N + BN - 1) / BN), (unsigned)((g.K + kc - 1) / kc));
+    const dim3 grid((unsigned)(((g.M + BM - 1) / BM) * ((g.N + BN - 1) / BN)), 1, (unsigned)((g.K + kc - 1) / kc));
     const bool ak = g.sak == 1, bnc = g.sbn == 1;
     if (!ak && g.sam != 1) { set_error("gemm: A must be contiguous along m or k"); return DINER_E_INVALID; }
     if (!bnc && g.sbk != 1) { set_error("gemm: B must be contiguous along k or n"); return DINER_E_INVALID; }
+    if (precision == DINER_PRECISION_F16X3) {
+        if (g.k_chunk > 0 && kc % f16g::BKH) { set_error("gemm: k_chunk must be a multiple of 32 in f16x3 mode"); return DINER_E_INVALID; }
+        if (ak && bnc) hipLaunchKernelGGL((f16g::gemm_f16x3_kernel<true, true>), grid, dim3(256), 0, st, a);
+        else if (ak && !bnc) hipLaunchKernelGGL((f16g::gemm_f16x3_kernel<true, false>), grid, dim3(256), 0, st, a);
+        else if (!ak && bnc) hipLaunchKernelGGL((f16g::gemm_f16x3_kernel<false, true>), grid, dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((f16g::gemm_f16x3_kernel<false, false>), grid, dim3(256), 0, st, a);
+        return check_launch("train::gemm_f16x3_kernel");
+    }
     if (ak && bnc) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, st, a);
     else if (ak && !bnc) hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, st, a);
     else if (!ak && bnc) hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, st, a);
@@ -358,10 +598,20 @@ using namespace train;
 
 int launch_train_gemm(const float *A, const float *B, const float *bias, const float *S, float *C, int64_t M, int N, int K,
                       int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc, int64_t lds, int relu_a, int relu_b,
-                      int accumulate, int atomic, int64_t k_chunk, hipStream_t st)
+                      int accumulate, int atomic, int64_t k_chunk, int precision, const unsigned int *amax_a,
+                      const unsigned int *amax_b, int exp_a, int exp_b, hipStream_t st)
 {
-    GemmArgs g{A, B, bias, S, C, M, N, K, sam, sak, sbk, sbn, ldc, lds, relu_a, relu_b, accumulate, atomic, k_chunk};
-    return launch_gemm(g, st);
+    GemmArgs g{A, B, bias, S, C, M, N, K, sam, sak, sbk, sbn, ldc, lds, relu_a, relu_b, accumulate, atomic, k_chunk, amax_a, amax_b, exp_a, exp_b};
+    return launch_gemm(g, precision, st);
+}
+
+int launch_train_amax(const float *x, int64_t n, unsigned int *out, hipStream_t st)
+{
+    if (hipMemsetAsync(out, 0, sizeof(unsigned int), st) != hipSuccess) { set_error("train_amax: memset failed"); return DINER_E_LAUNCH; }
+    if (n == 0) return DINER_OK;
+    const int64_t blocks = (n / 4 + 255) / 256;
+    hipLaunchKernelGGL(f16g::amax_kernel, dim3((unsigned)(blocks < 2048 ? (blocks > 0 ? blocks : 1) : 2048)), dim3(256), 0, st, x, n, out);
+    return check_launch("train::amax_kernel");
 }
 
 int launch_train_colsum(const float *dY, int64_t M, int N, int64_t ld, float *db, hipStream_t st)

@@ -179,13 +179,22 @@ int diner_render(const DinerScene *scene, const float *mlp_packed, const float *
  * (src/models/pixelnerf.py:55-145) + ResnetFC.forward (src/models/resnetfc.py:129-159), orchestrated by
  * diner_amd/training.py exactly like autograd orchestrates the reference's ATen ops.  Gradients: MLP
  * parameters and encoder.latent (NCHW); the sampler is @torch.no_grad in the reference. ------------------ */
-/* C[m][n] (+)= sum_k opA(A[m*sam + k*sak]) * opB(B[k*sbk + n*sbn]) (+ bias[n]) (* [S[m*lds + n] > 0]);
- * exact fp32 MFMA.  Each operand must be contiguous along one of its two indices; N % 4 == 0;
- * k_chunk (0 = no split) splits the contraction over blockIdx.z (use with atomic = 1). */
+/* C[m][n] (+)= sum_k opA(A[m*sam + k*sak]) * opB(B[k*sbk + n*sbn]) (+ bias[n]) (* [S[m*lds + n] > 0]).
+ * Each operand must be contiguous along one of its two indices; N % 4 == 0; k_chunk (0 = no split, else a
+ * multiple of 32) splits the contraction over blockIdx.z (use with atomic = 1).
+ * precision DINER_PRECISION_FP32: exact fp32 MFMA (amax / exp arguments ignored).
+ * precision DINER_PRECISION_F16X3: each operand element is multiplied by a power of two, split into fp16
+ * hi + lo, three fp16 MFMAs per product, fp32 accumulate (the arithmetic of diner_render_points' default
+ * mode).  The power of two is 2^exp_a (2^exp_b), or, when amax_a (amax_b) is not NULL, the one that maps the
+ * value stored there by diner_train_amax into [2^13, 2^14) -- meant for gradients, whose magnitude is
+ * arbitrary while fp16 has an absolute floor of 2^-24.  C is divided by the product of the two scales. */
 int diner_train_gemm(const float *A, const float *B, const float *bias, const float *S, float *C, int64_t M,
                      int32_t N, int32_t K, int64_t sam, int64_t sak, int64_t sbk, int64_t sbn, int64_t ldc,
                      int64_t lds, int32_t relu_a, int32_t relu_b, int32_t accumulate, int32_t atomic,
-                     int64_t k_chunk, void *stream);
+                     int64_t k_chunk, int32_t precision, const void *amax_a, const void *amax_b, int32_t exp_a,
+                     int32_t exp_b, void *stream);
+/* *amax_out (one 32-bit device word) = bit pattern of max |x[i]|, i < n (0 for an empty or all-zero tensor) */
+int diner_train_amax(const float *x, int64_t n, void *amax_out, void *stream);
 /* db[n] += sum_m dY[m*ld + n] */
 int diner_train_colsum(const float *dY, int64_t M, int32_t N, int64_t ld, float *db, void *stream);
 /* per (view, point) row = v*P + p of scene sb: in56 [R,56] (55 inputs of pixelnerf.py:128 + 0), z [R,512]
