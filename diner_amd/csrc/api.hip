@@ -36,6 +36,10 @@ int launch_train_gemm(const float *, const float *, const float *, const float *
                       int64_t, int64_t, int64_t, int, int, int, int, int64_t, int, const unsigned int *, const unsigned int *, int, int,
                       hipStream_t);
 int launch_train_amax(const float *, int64_t, unsigned int *, hipStream_t);
+int launch_train_colsum_amax(const float *, int64_t, int, int64_t, float *, unsigned int *, hipStream_t);
+int launch_train_split_panel(const float *, int, int64_t, int, int, void *, void *, hipStream_t);
+int launch_train_gemm_panel(const float *, int64_t, const void *, const void *, const float *, const float *, int64_t, const float *,
+                            int64_t, float *, int64_t, int64_t, int, int, const unsigned int *, int, int, hipStream_t);
 int launch_train_colsum(const float *, int64_t, int, int64_t, float *, hipStream_t);
 int launch_train_point_inputs(const DinerScene &, const float *, const float *, const float *, int64_t, int, int, float *, float *,
                               float *, hipStream_t);
@@ -231,6 +235,32 @@ int diner_train_amax(const float *x, int64_t n, void *amax_out, void *stream)
 {
     if (!x || !amax_out || n < 0) return bad("train_amax: bad argument");
     return launch_train_amax(x, n, (unsigned int *)amax_out, (hipStream_t)stream);
+}
+
+int diner_train_colsum_amax(const float *dY, int64_t M, int32_t N, int64_t ld, float *db, void *amax_out, void *stream)
+{
+    if (!dY || M < 0 || N <= 0 || (N & 3) || 256 % (N / 4) || (ld & 3)) return bad("train_colsum_amax: bad argument (N % 4 == 0 and (N/4) | 256)");
+    if (!db && !amax_out) return bad("train_colsum_amax: nothing to compute");
+    return launch_train_colsum_amax(dY, M, N, ld, db, (unsigned int *)amax_out, (hipStream_t)stream);
+}
+
+int diner_train_split_panel(const float *W, int32_t K, int64_t ld, int32_t transpose, int32_t exp, void *hi, void *lo, void *stream)
+{
+    if (!W || !hi || !lo || K <= 0 || ld <= 0) return bad("train_split_panel: bad argument");
+    if (exp < -60 || exp > 60) return bad("train_split_panel: scale exponent out of range");
+    return launch_train_split_panel(W, K, ld, transpose, exp, hi, lo, (hipStream_t)stream);
+}
+
+int diner_train_gemm_panel(const float *A, int64_t sam, const void *Bhi, const void *Blo, const float *bias, const float *S, int64_t lds,
+                           const float *addend, int64_t ldadd, float *C, int64_t ldc, int64_t M, int32_t K, int32_t relu_a,
+                           const void *amax_a, int32_t exp_a, int32_t exp_b, void *stream)
+{
+    if (!A || !Bhi || !Blo || !C) return bad("train_gemm_panel: NULL pointer");
+    if (M < 0 || K < 4 || (K & 3) || (sam & 3) || (ldc < DINER_D_HIDDEN)) return bad("train_gemm_panel: bad size (K % 4, sam % 4 must be 0)");
+    if (((uintptr_t)A & 15) || ((uintptr_t)Bhi & 15) || ((uintptr_t)Blo & 15)) return bad("train_gemm_panel: operands must be 16-byte aligned");
+    if (exp_a < -60 || exp_a > 60 || exp_b < -60 || exp_b > 60) return bad("train_gemm_panel: scale exponent out of range");
+    return launch_train_gemm_panel(A, sam, Bhi, Blo, bias, S, lds, addend, ldadd, C, ldc, M, K, relu_a, (const unsigned int *)amax_a, exp_a,
+                                   exp_b, (hipStream_t)stream);
 }
 
 int diner_train_colsum(const float *dY, int64_t M, int32_t N, int64_t ld, float *db, void *stream)

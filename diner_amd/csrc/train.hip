@@ -376,7 +376,254 @@ __global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, 
     m = wave_max(m);
     if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(out, __float_as_uint(m));
 }
+// One pass over a gradient matrix for both of its reductions: db[n] += sum_m dY[m][n] (bias gradient) and
+// *amax = max |dY| (scale of the f16x3 GEMMs that consume dY).  A thread owns one float4 of columns and every
+// (256 / (N/4))-th row, so a wave reads whole contiguous rows.  Requires N % 4 == 0 and (N/4) | 256.
+__global__ __launch_bounds__(256) void colsum_amax_kernel(const float *__restrict__ dY, int64_t M, int N, int64_t ld, float *__restrict__ db,
+                                                          unsigned int *__restrict__ amax)
+{
+    __shared__ f32x4 part[256];
+    const int groups = N >> 2, cg = threadIdx.x % groups, rl = threadIdx.x / groups, lanes = 256 / groups;
+    f32x4 sum = {0.f, 0.f, 0.f, 0.f};
+    float mx = 0.f;
+    for (int64_t m = (int64_t)blockIdx.x * lanes + rl; m < M; m += (int64_t)gridDim.x * lanes) {
+        const f32x4 v = *(const f32x4 *)(dY + m * ld + 4 * cg);
+        sum += v;
+        mx = fmaxf(fmaxf(fmaxf(mx, fabsf(v[0])), fmaxf(fabsf(v[1]), fabsf(v[2]))), fabsf(v[3]));
+    }
+    if (amax) {
+        mx = wave_max(mx);
+        if ((threadIdx.x & 63) == 0 && mx > 0.f) atomicMax(amax, __float_as_uint(mx));
+    }
+    if (db) {
+        part[threadIdx.x] = sum;
+        __syncthreads();
+        if (rl == 0) {
+            for (int i = 1; i < lanes; ++i) sum += part[i * groups + cg];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(db + 4 * cg + j, sum[j]);
+        }
+    }
+}
 }  // namespace f16g
+
+// ---- weight-panel GEMM (f16x3): C[128 rows x 256 cols] per workgroup, B = a 512-column weight matrix given as
+// pre-split fp16 hi/lo planes (diner_train_split_panel) ---------------------------------------------------------
+// The forward and the dX GEMMs of the training path multiply a huge streamed activation / gradient matrix by a
+// 512 x K weight.  In gemm_f16x3_kernel every A tile is split into fp16 hi/lo by four workgroups and every weight
+// tile by thousands, and that fp32->fp16x2 conversion (VALU) costs more than the MFMAs (timing-only ablation:
+// 1.70 ms with, 0.95 ms without it).  Here the weights arrive already split (no VALU: 16-byte loads become
+// 16-byte LDS units), a workgroup owns 256 columns so A is split twice instead of four times, and the two
+// workgroups of a row panel sit on one XCD (one HBM read of A).  8 waves as 2 x 4, 64 x 64 outputs each, k-steps
+// of 32, LDS double-buffered; A is staged two steps ahead (HBM), the weights one step ahead (L2).
+namespace panel {
+using f16g::h4;
+using f16g::h8;
+constexpr int PM = 128, PNW = 256, PN = 512, PK = 32;
+constexpr int A_UNITS = (PK / 8) * PM, B_UNITS = (PK / 8) * PNW;  // 16-byte units (u = k/8, row) per image and stage
+constexpr int STAGE_UNITS = 2 * A_UNITS + 2 * B_UNITS;            // 48 KiB
+
+struct PanelArgs {
+    const float *A;
+    int64_t sam;                 // A[m*sam + k], k contiguous
+    const _Float16 *Bhi, *Blo;   // panel layout [k/32][512][32], zero-padded to a multiple of 32 in k, scaled by 2^exp_b
+    const float *bias, *S, *addend;
+    float *C;
+    int64_t M;
+    int K;
+    int64_t ldc, lds_, ldadd;
+    int relu_a;
+    const unsigned int *amax_a;
+    int exp_a, exp_b;
+};
+
+__device__ __forceinline__ int unit(int u, int row, int rows) { return u * rows + (row ^ (4 * u)); }
+
+struct StageA {  // 128 x 32 fp32 of A: two float4 per thread
+    f32x4 a[2];
+    unsigned ok;
+};
+struct StageB {  // 256 x 32 halfs x {hi, lo} of the weights: two 16-byte units per plane and thread
+    h8 bh[2], bl[2];
+};
+
+__device__ __forceinline__ void load_a(StageA &st, const PanelArgs &g, int64_t m0, int k0, int tid)
+{
+    st.ok = 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 512 * i;
+        const int64_t m = m0 + (idx >> 3);
+        const int k = k0 + (idx & 7) * 4;
+        st.ok |= (unsigned)(m < g.M && k < g.K) << i;
+        st.a[i] = *(const f32x4 *)(g.A + (m < g.M ? m : g.M - 1) * g.sam + (k < g.K ? k : g.K - 4));
+    }
+}
+__device__ __forceinline__ void load_b(StageB &st, const PanelArgs &g, int n0, int k0, int tid)
+{
+    const int64_t off = ((int64_t)(k0 / PK) * PN + n0) * PK;  // this workgroup's 256 rows of the k-step: 16 KiB contiguous
+    const h8 *ph = (const h8 *)(g.Bhi + off), *pl = (const h8 *)(g.Blo + off);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        st.bh[i] = ph[tid + 512 * i];
+        st.bl[i] = pl[tid + 512 * i];
+    }
+}
+__device__ __forceinline__ void store_a(h8 *T, const StageA &st, float floor_, float sc, int tid)
+{
+    h8 *Ahi = T, *Alo = T + A_UNITS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 512 * i, row = idx >> 3, kq = (idx & 7) * 4;
+        h4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t = ((st.ok >> i) & 1u) ? fmaxf(st.a[i][j] * sc, floor_) : 0.0f;
+            hi[j] = (_Float16)t;
+            lo[j] = (_Float16)(t - (float)hi[j]);
+        }
+        const int o = unit(kq >> 3, row, PM) * 8 + (kq & 4);
+        *(h4 *)((_Float16 *)Ahi + o) = hi;
+        *(h4 *)((_Float16 *)Alo + o) = lo;
+    }
+}
+__device__ __forceinline__ void store_b(h8 *T, const StageB &st, int tid)
+{
+    h8 *Bhi = T + 2 * A_UNITS, *Blo = T + 2 * A_UNITS + B_UNITS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int q = tid + 512 * i, n = q >> 2, u = q & 3;  // plane order: [n][32] = four units per row
+        Bhi[unit(u, n, PNW)] = st.bh[i];
+        Blo[unit(u, n, PNW)] = st.bl[i];
+    }
+}
+
+__global__ __launch_bounds__(512) void gemm_panel_kernel(PanelArgs g)
+{
+    __shared__ h8 T[2][STAGE_UNITS];  // 2 x 48 KiB
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the two column halves of a row panel are consecutive workgroups of ONE XCD (ids congruent mod 8)
+    int64_t m0;
+    int n0;
+    {
+        const int64_t gm = (g.M + PM - 1) / PM, lin = blockIdx.x, full = gm / 8 * 8;
+        int64_t mt, nb;
+        if (lin < full * 2) { const int64_t j = lin / 8; nb = j & 1; mt = (j >> 1) * 8 + lin % 8; }
+        else { const int64_t q = lin - full * 2; mt = full + (q >> 1); nb = q & 1; }
+        m0 = mt * PM;
+        n0 = (int)nb * PNW;
+    }
+    const int wm = (wave >> 2) * 64, wn = (wave & 3) * 64;
+    float sa, ia, sb, ib;
+    f16g::scale_of(g.amax_a, g.exp_a, sa, ia);
+    f16g::scale_of(nullptr, g.exp_b, sb, ib);
+    const float fa = g.relu_a ? 0.0f : -__builtin_inff();
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    const int steps = (g.K + PK - 1) / PK;
+    const int r = lane & 31, h = lane >> 5;
+    StageA sta[2];
+    StageB stb;
+    load_a(sta[0], g, m0, 0, tid);
+    load_b(stb, g, n0, 0, tid);
+    load_a(sta[1], g, m0, PK, tid);  // all-invalid (zeros) when there is no second step
+    store_a(T[0], sta[0], fa, sa, tid);
+    store_b(T[0], stb, tid);
+    __syncthreads();
+#define DINER_PANEL_STEP(SL)                                                                                     \
+    {                                                                                                            \
+        if (t + 1 < steps) load_b(stb, g, n0, (t + 1) * PK, tid);                                                \
+        if (t + 2 < steps) load_a(sta[SL], g, m0, (t + 2) * PK, tid);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        {                                                                                                        \
+            const h8 *Ahi = T[SL], *Alo = T[SL] + A_UNITS, *Bhi = T[SL] + 2 * A_UNITS, *Blo = Bhi + B_UNITS;     \
+            _Pragma("unroll") for (int ks = 0; ks < PK / 16; ++ks) {                                             \
+                const int u = ks * 2 + h;                                                                        \
+                h8 ah[2], al[2], bh[2], bl[2];                                                                   \
+                _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                  \
+                    const int oa = unit(u, wm + 32 * q + r, PM), ob = unit(u, wn + 32 * q + r, PNW);             \
+                    ah[q] = Ahi[oa]; al[q] = Alo[oa];                                                            \
+                    bh[q] = Bhi[ob]; bl[q] = Blo[ob];                                                            \
+                }                                                                                                \
+                _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                                 \
+                    _Pragma("unroll") for (int tb = 0; tb < 2; ++tb) {                                           \
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ta], bh[tb], acc[ta][tb], 0, 0, 0);  \
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ta], bl[tb], acc[ta][tb], 0, 0, 0);  \
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ta], bh[tb], acc[ta][tb], 0, 0, 0);  \
+                    }                                                                                            \
+            }                                                                                                    \
+        }                                                                                                        \
+        /* no scheduling fence here: the split of A(t+1) (its loads are a step old) may slide between the MFMAs */ \
+        if (t + 1 < steps) {                                                                                     \
+            store_a(T[1 - SL], sta[1 - SL], fa, sa, tid);                                                        \
+            store_b(T[1 - SL], stb, tid);                                                                        \
+        }                                                                                                        \
+        __syncthreads();                                                                                         \
+    }
+    for (int t = 0; t < steps; ++t) {
+        DINER_PANEL_STEP(0)
+        if (++t >= steps) break;
+        DINER_PANEL_STEP(1)
+    }
+#undef DINER_PANEL_STEP
+    const float unscale = ia * ib;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int n = n0 + wn + tb * 32 + (lane & 31);
+        const float bias = g.bias ? g.bias[n] : 0.0f;
+#pragma unroll
+        for (int ta = 0; ta < 2; ++ta) {
+            const int64_t mb = m0 + wm + ta * 32 + 4 * h;
+            float old[16], msk[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { old[i] = 0.0f; msk[i] = 1.0f; }
+            if (g.addend) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t m = mb + (i & 3) + 8 * (i >> 2);
+                    old[i] = g.addend[(m < g.M ? m : g.M - 1) * g.ldadd + n];
+                }
+            }
+            if (g.S) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const int64_t m = mb + (i & 3) + 8 * (i >> 2);
+                    msk[i] = g.S[(m < g.M ? m : g.M - 1) * g.lds_ + n];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int64_t m = mb + (i & 3) + 8 * (i >> 2);
+                if (m >= g.M) continue;
+                float v = acc[ta][tb][i] * unscale + bias;
+                v = msk[i] > 0.0f ? v : 0.0f;
+                g.C[m * g.ldc + n] = old[i] + v;
+            }
+        }
+    }
+}
+
+// B[n][k] = (transpose ? W[k*ld + n] : W[n*ld + k]) * 2^exp -> fp16 hi / lo planes in panel layout [k/32][512][32]
+__global__ void split_panel_kernel(const float *__restrict__ W, int K, int64_t ld, int transpose, int exp_, _Float16 *__restrict__ hi,
+                                   _Float16 *__restrict__ lo)
+{
+    const int kpad = (K + PK - 1) / PK * PK;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (int64_t)PN * kpad) return;
+    const int kk = (int)(i % PK), n = (int)((i / PK) % PN), ks = (int)(i / (PK * PN)), k = ks * PK + kk;
+    float sc, inv;
+    f16g::scale_of(nullptr, exp_, sc, inv);
+    const float v = k < K ? (transpose ? W[(int64_t)k * ld + n] : W[(int64_t)n * ld + k]) * sc : 0.0f;
+    const _Float16 hv = (_Float16)v;
+    hi[i] = hv;
+    lo[i] = (_Float16)(v - (float)hv);
+}
+}  // namespace panel
 
 int launch_gemm(const GemmArgs &g, int precision, hipStream_t st)
 {
@@ -603,6 +850,34 @@ int launch_train_gemm(const float *A, const float *B, const float *bias, const f
 {
     GemmArgs g{A, B, bias, S, C, M, N, K, sam, sak, sbk, sbn, ldc, lds, relu_a, relu_b, accumulate, atomic, k_chunk, amax_a, amax_b, exp_a, exp_b};
     return launch_gemm(g, precision, st);
+}
+
+int launch_train_split_panel(const float *W, int K, int64_t ld, int transpose, int exp_, void *hi, void *lo, hipStream_t st)
+{
+    const int64_t n = (int64_t)panel::PN * ((K + panel::PK - 1) / panel::PK * panel::PK);
+    hipLaunchKernelGGL(panel::split_panel_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, W, K, ld, transpose, exp_,
+                       (_Float16 *)hi, (_Float16 *)lo);
+    return check_launch("train::split_panel_kernel");
+}
+
+int launch_train_gemm_panel(const float *A, int64_t sam, const void *Bhi, const void *Blo, const float *bias, const float *S,
+                            int64_t lds, const float *addend, int64_t ldadd, float *C, int64_t ldc, int64_t M, int K, int relu_a,
+                            const unsigned int *amax_a, int exp_a, int exp_b, hipStream_t st)
+{
+    if (M == 0) return DINER_OK;
+    panel::PanelArgs g{A, sam, (const _Float16 *)Bhi, (const _Float16 *)Blo, bias, S, addend, C, M, K, ldc, lds, ldadd, relu_a, amax_a, exp_a, exp_b};
+    hipLaunchKernelGGL(panel::gemm_panel_kernel, dim3((unsigned)(2 * ((M + panel::PM - 1) / panel::PM))), dim3(512), 0, st, g);
+    return check_launch("train::gemm_panel_kernel");
+}
+
+int launch_train_colsum_amax(const float *dY, int64_t M, int N, int64_t ld, float *db, unsigned int *amax, hipStream_t st)
+{
+    if (amax && hipMemsetAsync(amax, 0, sizeof(unsigned int), st) != hipSuccess) { set_error("train_colsum_amax: memset failed"); return DINER_E_LAUNCH; }
+    if (M == 0) return DINER_OK;
+    const int lanes = 256 / (N / 4);
+    const int64_t blocks = (M + lanes - 1) / lanes;
+    hipLaunchKernelGGL(f16g::colsum_amax_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048)), dim3(256), 0, st, dY, M, N, ld, db, amax);
+    return check_launch("train::colsum_amax_kernel");
 }
 
 int launch_train_amax(const float *x, int64_t n, unsigned int *out, hipStream_t st)

@@ -52,20 +52,56 @@ def amax_of(t, prec):
     return out
 
 
-def linear_fwd(X, W, b, out, relu_in=False, accumulate=False, prec=0):
-    """out[M,N] (+)= relu?(X[M,K]) W[N,K]^T + b."""
+def split_panel(W, transpose, prec):
+    """Weight operand of the panel GEMM (f16x3 mode): fp16 hi/lo planes of B[n][k] = W[n][k] (forward) or W[k][n]
+    (transpose: the dX GEMM), 512 rows each; None when the panel kernel does not apply (fp32 mode, not 512 columns)."""
+    n_rows, K = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
+    if prec == 0 or n_rows != HID:
+        return None
+    kpad = (K + 31) // 32 * 32
+    planes = torch.empty((2, HID * kpad), dtype=torch.float16, device=W.device)
+    check(_lib.lib().diner_train_split_panel(_p(W), K, W.stride(0), int(transpose), EXP_W, _p(planes[0]), _p(planes[1]), _st(W.device)),
+          "diner_train_split_panel")
+    return planes
+
+
+def _panel(A, planes, bias, S, addend, out, relu_a, amax, exp_a):
+    M, K = A.shape
+    check(_lib.lib().diner_train_gemm_panel(_p(A), A.stride(0), _p(planes[0]), _p(planes[1]), _p(bias), _p(S), 0 if S is None else S.stride(0),
+                                            _p(addend), 0 if addend is None else addend.stride(0), _p(out), out.stride(0), M, K, int(relu_a),
+                                            _p(amax), exp_a, EXP_W, _st(out.device)), "diner_train_gemm_panel")
+
+
+def colsum_amax(dY, db, prec):
+    """db += column sums of dY (the bias gradient) and, in f16x3 mode, the device word with max|dY| -- one pass."""
+    M, N = dY.shape
+    out = torch.empty(1, dtype=torch.int32, device=dY.device) if prec else None
+    check(_lib.lib().diner_train_colsum_amax(_p(dY), M, N, dY.stride(0), _p(db), _p(out), _st(dY.device)), "diner_train_colsum_amax")
+    return out
+
+
+def linear_fwd(X, W, b, out, relu_in=False, addend=None, prec=0, panel=None):
+    """out[M,N] = addend + relu?(X[M,K]) W[N,K]^T + b   (addend may be ``out`` itself)."""
     M, K = X.shape
     N = W.shape[0]
-    _gemm(X, W, b, None, out, M, N, K, X.stride(0), 1, 1, W.stride(0), out.stride(0), 0, relu_a=int(relu_in), accumulate=int(accumulate),
+    if panel is not None:
+        return _panel(X, panel, b, None, addend, out, relu_in, None, EXP_ACT)
+    if addend is not None and addend is not out:
+        out.copy_(addend)
+    _gemm(X, W, b, None, out, M, N, K, X.stride(0), 1, 1, W.stride(0), out.stride(0), 0, relu_a=int(relu_in), accumulate=int(addend is not None),
           prec=prec, exp_a=EXP_ACT, exp_b=EXP_W)
 
 
-def linear_bwd_x(dY, W, mask_src, out, accumulate=False, prec=0, amax=None):
-    """out[M,K] (+)= (dY[M,N] W[N,K]) * [mask_src > 0]."""
+def linear_bwd_x(dY, W, mask_src, out, addend=None, prec=0, amax=None, panel=None):
+    """out[M,K] = addend + (dY[M,N] W[N,K]) * [mask_src > 0]   (addend may be ``out`` itself)."""
     M, N = dY.shape
     K = W.shape[1]
+    if panel is not None:
+        return _panel(dY, panel, None, mask_src, addend, out, False, amax, 0)
+    if addend is not None and addend is not out:
+        out.copy_(addend)
     _gemm(dY, W, None, mask_src, out, M, K, N, dY.stride(0), 1, W.stride(0), 1, out.stride(0),
-          0 if mask_src is None else mask_src.stride(0), accumulate=int(accumulate), prec=prec, amax_a=amax, exp_b=EXP_W)
+          0 if mask_src is None else mask_src.stride(0), accumulate=int(addend is not None), prec=prec, amax_a=amax, exp_b=EXP_W)
 
 
 def linear_bwd_w(dY, X, dW, db, relu_x=False, prec=0, amax=None):
@@ -107,20 +143,22 @@ class _RenderFn(torch.autograd.Function):
         rgbsigma = f(SB, NR, K, 4)
         prec = _lib.PRECISIONS[renderer.precision]
         saved = []
+        wp = {i: split_panel(prm[i], False, prec) for i in (2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26)}
+        wp[0] = split_panel(w_in56, False, prec)
         for sb in range(SB):
             in56, zl, taps = f(R, 56), f(R, HID), f(R, 8)
             check(L.diner_train_point_inputs(C.byref(scene), _p(lat), _p(rays), _p(z), NR, K, sb, _p(in56), _p(zl), _p(taps), st),
                   "diner_train_point_inputs")
             x = f(R, HID)
-            linear_fwd(in56, w_in56, prm[1], x, prec=prec)                                  # resnetfc.py:139
+            linear_fwd(in56, w_in56, prm[1], x, prec=prec, panel=wp[0])                          # resnetfc.py:139
             xs, nets = [], []
             for b in range(3):
-                xb = x.clone()
-                linear_fwd(zl, prm[2 + 2 * b], prm[3 + 2 * b], xb, accumulate=True, prec=prec)      # :152-153
+                xb = f(R, HID)
+                linear_fwd(zl, prm[2 + 2 * b], prm[3 + 2 * b], xb, addend=x, prec=prec, panel=wp[2 + 2 * b])          # :152-153
                 net = f(R, HID)
-                linear_fwd(xb, prm[8 + 4 * b], prm[9 + 4 * b], net, relu_in=True, prec=prec)        # :62
-                x = xb.clone()
-                linear_fwd(net, prm[10 + 4 * b], prm[11 + 4 * b], x, relu_in=True, accumulate=True, prec=prec)  # :63,:69
+                linear_fwd(xb, prm[8 + 4 * b], prm[9 + 4 * b], net, relu_in=True, prec=prec, panel=wp[8 + 4 * b])      # :62
+                x = f(R, HID)
+                linear_fwd(net, prm[10 + 4 * b], prm[11 + 4 * b], x, relu_in=True, addend=xb, prec=prec, panel=wp[10 + 4 * b])  # :63,:69
                 xs.append(xb)
                 nets.append(net)
             xbar = f(P, HID)
@@ -128,9 +166,9 @@ class _RenderFn(torch.autograd.Function):
             xbars, pnets = [], []
             for b in range(3, 5):
                 net = f(P, HID)
-                linear_fwd(xbar, prm[8 + 4 * b], prm[9 + 4 * b], net, relu_in=True, prec=prec)
-                nxt = xbar.clone()
-                linear_fwd(net, prm[10 + 4 * b], prm[11 + 4 * b], nxt, relu_in=True, accumulate=True, prec=prec)
+                linear_fwd(xbar, prm[8 + 4 * b], prm[9 + 4 * b], net, relu_in=True, prec=prec, panel=wp[8 + 4 * b])
+                nxt = f(P, HID)
+                linear_fwd(net, prm[10 + 4 * b], prm[11 + 4 * b], nxt, relu_in=True, addend=xbar, prec=prec, panel=wp[10 + 4 * b])
                 xbars.append(xbar)
                 pnets.append(net)
                 xbar = nxt
@@ -170,46 +208,48 @@ class _RenderFn(torch.autograd.Function):
         g_in56 = torch.zeros_like(ctx.w_in56)
         SBl, NVl, Cl, hl, wl = ctx.lat_shape
         d_lat_nhwc = torch.zeros((SBl, NVl, hl, wl, Cl), dtype=torch.float32, device=dev)
+        wt = {i: split_panel(prm[i], True, prec) for i in (2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28)}
         for sb in range(SB):
             in56, zl, taps, xs, nets, xbars, pnets, xbar5, out = ctx.saved_acts[sb]
             d_out = f(P, 4)
             check(L.diner_train_head(_p(out), _p(rgbsigma[sb]), _p(d_rgbsigma[sb]), P * 4, _p(d_out), 1, st), "diner_train_head(bwd)")
-            a_out = amax_of(d_out, prec)
-            linear_bwd_w(d_out, xbar5, g[28], g[29], relu_x=True, prec=prec, amax=a_out)
+            a_out = colsum_amax(d_out, g[29], prec)
+            linear_bwd_w(d_out, xbar5, g[28], None, relu_x=True, prec=prec, amax=a_out)
             d_x = f(P, HID)
-            linear_bwd_x(d_out, prm[28], xbar5, d_x, prec=prec, amax=a_out)
+            linear_bwd_x(d_out, prm[28], xbar5, d_x, prec=prec, amax=a_out, panel=wt[28])
             for i, b in ((1, 4), (0, 3)):                                         # post-mean blocks, reversed
                 d_net = f(P, HID)
-                a_x = amax_of(d_x, prec)
-                linear_bwd_x(d_x, prm[10 + 4 * b], pnets[i], d_net, prec=prec, amax=a_x)
-                linear_bwd_w(d_x, pnets[i], g[10 + 4 * b], g[11 + 4 * b], relu_x=True, prec=prec, amax=a_x)
-                d_prev = d_x.clone()
-                a_net = amax_of(d_net, prec)
-                linear_bwd_x(d_net, prm[8 + 4 * b], xbars[i], d_prev, accumulate=True, prec=prec, amax=a_net)
-                linear_bwd_w(d_net, xbars[i], g[8 + 4 * b], g[9 + 4 * b], relu_x=True, prec=prec, amax=a_net)
+                a_x = colsum_amax(d_x, g[11 + 4 * b], prec)
+                linear_bwd_x(d_x, prm[10 + 4 * b], pnets[i], d_net, prec=prec, amax=a_x, panel=wt[10 + 4 * b])
+                linear_bwd_w(d_x, pnets[i], g[10 + 4 * b], None, relu_x=True, prec=prec, amax=a_x)
+                d_prev = f(P, HID)
+                a_net = colsum_amax(d_net, g[9 + 4 * b], prec)
+                linear_bwd_x(d_net, prm[8 + 4 * b], xbars[i], d_prev, addend=d_x, prec=prec, amax=a_net, panel=wt[8 + 4 * b])
+                linear_bwd_w(d_net, xbars[i], g[8 + 4 * b], None, relu_x=True, prec=prec, amax=a_net)
                 d_x = d_prev
             d_xv = f(R, HID)
             check(L.diner_train_view_mean(_p(d_x), P * HID, NV, _p(d_xv), 1, st), "diner_train_view_mean(bwd)")
             d_zl = torch.zeros((R, HID), dtype=torch.float32, device=dev)
-            a_xv = amax_of(d_xv, prec)
             for b in (2, 1, 0):                                                   # per-view blocks, reversed
                 d_net = f(R, HID)
-                linear_bwd_x(d_xv, prm[10 + 4 * b], nets[b], d_net, prec=prec, amax=a_xv)
-                linear_bwd_w(d_xv, nets[b], g[10 + 4 * b], g[11 + 4 * b], relu_x=True, prec=prec, amax=a_xv)
-                d_xs = d_xv.clone()
-                a_net = amax_of(d_net, prec)
-                linear_bwd_x(d_net, prm[8 + 4 * b], xs[b], d_xs, accumulate=True, prec=prec, amax=a_net)
-                linear_bwd_w(d_net, xs[b], g[8 + 4 * b], g[9 + 4 * b], relu_x=True, prec=prec, amax=a_net)
-                a_xv = amax_of(d_xs, prec)
-                linear_bwd_w(d_xs, zl, g[2 + 2 * b], g[3 + 2 * b], prec=prec, amax=a_xv)  # lin_z[b]
-                linear_bwd_x(d_xs, prm[2 + 2 * b], None, d_zl, accumulate=True, prec=prec, amax=a_xv)
+                a_xv = colsum_amax(d_xv, g[11 + 4 * b], prec)
+                linear_bwd_x(d_xv, prm[10 + 4 * b], nets[b], d_net, prec=prec, amax=a_xv, panel=wt[10 + 4 * b])
+                linear_bwd_w(d_xv, nets[b], g[10 + 4 * b], None, relu_x=True, prec=prec, amax=a_xv)
+                d_xs = f(R, HID)
+                a_net = colsum_amax(d_net, g[9 + 4 * b], prec)
+                linear_bwd_x(d_net, prm[8 + 4 * b], xs[b], d_xs, addend=d_xv, prec=prec, amax=a_net, panel=wt[8 + 4 * b])
+                linear_bwd_w(d_net, xs[b], g[8 + 4 * b], None, relu_x=True, prec=prec, amax=a_net)
+                a_xs = colsum_amax(d_xs, g[3 + 2 * b], prec)
+                linear_bwd_w(d_xs, zl, g[2 + 2 * b], None, prec=prec, amax=a_xs)          # lin_z[b]
+                linear_bwd_x(d_xs, prm[2 + 2 * b], None, d_zl, addend=d_zl, prec=prec, amax=a_xs, panel=wt[2 + 2 * b])
                 d_xv = d_xs
-            linear_bwd_w(d_xv, in56, g_in56, g[1], prec=prec, amax=a_xv)           # lin_in
+            linear_bwd_w(d_xv, in56, g_in56, None, prec=prec, amax=a_xs)           # lin_in (its d_xv is lin_z[0]'s d_xs)
             check(L.diner_train_bilinear_scatter(_p(d_zl), _p(taps), P, HID, scene.h, scene.w, NV, sb, _p(d_lat_nhwc), st),
                   "diner_train_bilinear_scatter")
         d_lat = torch.empty(ctx.lat_shape, dtype=torch.float32, device=dev)
         check(L.diner_train_nhwc_to_nchw(_p(d_lat_nhwc), SBl * NVl, Cl, hl, wl, _p(d_lat), st), "diner_train_nhwc_to_nchw")
         g[0] = g_in56[:, :55].contiguous()
+        g[1] = g[3].clone()  # lin_in's bias sees the same dY as lin_z[0]'s: x = lin_in(..) + lin_z[0](z)
         return (None, None, None, None, d_lat) + tuple(g)
 
 

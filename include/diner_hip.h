@@ -195,6 +195,23 @@ int diner_train_gemm(const float *A, const float *B, const float *bias, const fl
                      int32_t exp_b, void *stream);
 /* *amax_out (one 32-bit device word) = bit pattern of max |x[i]|, i < n (0 for an empty or all-zero tensor) */
 int diner_train_amax(const float *x, int64_t n, void *amax_out, void *stream);
+/* Both reductions of a gradient matrix in one pass: db[n] += sum_m dY[m*ld + n] (skipped if db is NULL) and
+ * *amax_out as diner_train_amax (skipped if NULL).  N % 4 == 0 and N/4 must divide 256. */
+int diner_train_colsum_amax(const float *dY, int64_t M, int32_t N, int64_t ld, float *db, void *amax_out, void *stream);
+/* Weight operand of diner_train_gemm_panel: B[n][k] = (transpose ? W[k*ld + n] : W[n*ld + k]) * 2^exp, n < 512,
+ * k < K, as fp16 hi / lo planes of 512 * ceil32(K) halfs each, laid out [k/32][512][32] (one k-step of the GEMM
+ * is one contiguous 32-KiB piece per plane), zero-padded in k. */
+int diner_train_split_panel(const float *W, int32_t K, int64_t ld, int32_t transpose, int32_t exp, void *hi, void *lo,
+                            void *stream);
+/* C[m][n] = addend[m*ldadd + n] + (sum_k opA(A[m*sam + k]) * B[n][k] + bias[n]) * [S[m*lds + n] > 0], n < 512:
+ * the forward and dX GEMMs of the training path in f16x3 arithmetic (see diner_train_gemm) with the weights
+ * arriving pre-split (no conversion work for them in the GEMM) and A split twice instead of four times.  opA = relu if relu_a,
+ * scaled by 2^exp_a or by *amax_a like diner_train_gemm; exp_b must be the exponent given to
+ * diner_train_split_panel.  bias, S, addend may be NULL; addend may alias C. */
+int diner_train_gemm_panel(const float *A, int64_t sam, const void *Bhi, const void *Blo, const float *bias,
+                           const float *S, int64_t lds, const float *addend, int64_t ldadd, float *C, int64_t ldc,
+                           int64_t M, int32_t K, int32_t relu_a, const void *amax_a, int32_t exp_a, int32_t exp_b,
+                           void *stream);
 /* db[n] += sum_m dY[m*ld + n] */
 int diner_train_colsum(const float *dY, int64_t M, int32_t N, int64_t ld, float *db, void *stream);
 /* per (view, point) row = v*P + p of scene sb: in56 [R,56] (55 inputs of pixelnerf.py:128 + 0), z [R,512]

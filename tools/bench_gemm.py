@@ -24,10 +24,15 @@ def main(M=655360, reps=3):
         a = T.amax_of(dY, prec)
         cases = {
             "fwd": lambda: T.linear_fwd(X, W, b, out, relu_in=True, prec=prec),
-            "fwd+acc": lambda: T.linear_fwd(X, W, b, out, relu_in=True, accumulate=True, prec=prec),
+            "fwd+acc": lambda: T.linear_fwd(X, W, b, out, relu_in=True, addend=out, prec=prec),
             "dX": lambda: T.linear_bwd_x(dY, W, X, out, prec=prec, amax=a),
             "dW": lambda: T.linear_bwd_w(dY, X, dw, None, relu_x=True, prec=prec, amax=a),
         }
+        if prec:
+            wp, wtp = T.split_panel(W, False, prec), T.split_panel(W, True, prec)
+            cases["fwd panel"] = lambda: T.linear_fwd(X, W, b, out, relu_in=True, prec=prec, panel=wp)
+            cases["fwd+add panel"] = lambda: T.linear_fwd(X, W, b, out, relu_in=True, addend=out, prec=prec, panel=wp)
+            cases["dX panel"] = lambda: T.linear_bwd_x(dY, W, X, out, prec=prec, amax=a, panel=wtp)
         for name, fn in cases.items():
             fn()
             torch.cuda.synchronize()
@@ -38,7 +43,7 @@ def main(M=655360, reps=3):
             e1.record()
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / reps
-            print(f"prec={'f16x3' if prec else 'fp32'} {name:8s} {ms:7.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s", flush=True)
+            print(f"prec={'f16x3' if prec else 'fp32'} {name:14s} {ms:7.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s", flush=True)
 
 
 if __name__ == "__main__":
