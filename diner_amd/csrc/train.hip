@@ -7,14 +7,16 @@
 //
 // Unlike the fused inference kernels this path is layer by layer: every layer's input must be kept for the
 // weight gradients anyway, so activations live in HBM as row-major [rows, 512] fp32 matrices (rows = point x
-// view, ~10 GB for a 4096-ray x 40-sample x 4-view step -- 288 GB of HBM make that a non-issue) and all linear
-// algebra is ONE exact fp32 MFMA GEMM kernel (v_mfma_f32_32x32x2_f32) with stride-described operands:
-//     C[m][n] (+)= sum_k opA(A[m*sam + k*sak]) * opB(B[k*sbk + n*sbn])      (+ bias[n]) (* [S[m][n] > 0])
-//   forward      Y  = relu?(X) W^T + b (+ Y)          A = X (k contiguous), B = W (k contiguous)
-//   backward dX  dX = (dY W) * [S > 0] (+ dX)         A = dY (k contiguous), B = W (n contiguous)
-//   backward dW  dW += dY^T relu?(X), split over rows A = dY (m contiguous), B = X (n contiguous), atomic C
+// view, ~24 GB for a 4096-ray x 40-sample x 4-view step -- 288 GB of HBM make that a non-issue).  GEMMs:
+//   gemm_kernel        exact fp32 MFMA (v_mfma_f32_32x32x2_f32), stride-described operands:
+//                        C[m][n] (+)= sum_k opA(A[m*sam + k*sak]) * opB(B[k*sbk + n*sbn])  (+ bias[n]) (* [S[m][n] > 0])
+//                        forward      Y  = relu?(X) W^T + b (+ Y)          A = X (k contiguous), B = W (k contiguous)
+//                        backward dX  dX = (dY W) * [S > 0] (+ dX)         A = dY (k contiguous), B = W (n contiguous)
+//                        backward dW  dW += dY^T relu?(X), split over rows A = dY (m contiguous), B = X (n contiguous), atomic C
+//   gemm_f16x3_kernel  the same contract in fp32-grade fp16 arithmetic (hi/lo split, 3 MFMAs per product), used for dW
+//   gemm_panel_kernel  forward / dX in f16x3 arithmetic with the weight pre-split into fp16 planes
 // plus small per-point kernels (inputs/bilinear gather, view mean, head, compositing backward, bilinear
-// scatter-add).  Correctness first: ~40-60 TFLOP/s GEMMs, not the tuned inference path.
+// scatter-add, bias-gradient + max|.| reduction).  Measured rates: DESIGN.md section 4.4.
 #include "common.hpp"
 
 namespace diner {

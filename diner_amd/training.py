@@ -3,10 +3,10 @@
 The reference trains through ``NeRFRendererDGS.composite`` and ``PixelNeRF.forward`` with PyTorch autograd
 (``DINER.calc_losses``, reference src/models/diner.py:217-290; the sampler is ``@torch.no_grad``,
 src/models/nerf_renderer.py:65).  Here the same graph is evaluated by the HIP building blocks of
-``diner_amd/csrc/train.hip`` (one exact fp32-MFMA GEMM kernel + small per-point kernels, all through the C ABI);
-this module only orchestrates them the way autograd orchestrates ATen ops: a forward that keeps every layer's
-input, and a hand-written backward producing gradients for the fusion-MLP parameters and ``encoder.latent``.
-PyTorch supplies buffers, clones and the autograd hook -- no arithmetic of the path.
+``diner_amd/csrc/train.hip`` (MFMA GEMM kernels in the renderer's precision + small per-point kernels, all through
+the C ABI); this module only orchestrates them the way autograd orchestrates ATen ops: a forward that keeps every
+layer's input, and a hand-written backward producing gradients for the fusion-MLP parameters and
+``encoder.latent``.  PyTorch supplies buffers and the autograd hook -- no arithmetic of the path.
 """
 from __future__ import annotations
 
