@@ -189,3 +189,46 @@ def test_cache_invalidation_on_new_encode(dev):
     ref2 = run_oracle(sc2, w, rays, K, NC, G, noise)
     agree(out2.fine.rgb.cpu().numpy()[0], ref2["rgb"])
     assert not torch.equal(out1.fine.rgb, out2.fine.rgb)
+
+
+def test_headline_size_frame(dev):
+    """BASELINE.json's headline configuration at full size (512x512 target, 4 source views 512x512, K=128, G=48,
+    NC=1000): the whole frame in one launch through size-independent properties (finite, colour in [0,1], depth
+    inside [near, far], weights >= 0 with sum <= 1, bit-identical on a re-run with the same seed), and a strided
+    sample of the same frame against the oracle with injected noise."""
+    from diner_amd import NeRFRendererDGS
+    from diner_amd.model_stub import model_from_scene
+    from oracle.oracle import Oracle
+    H = W = 512
+    NV, K, G, NC = 4, 128, 48, 1000
+    sc = synth.make_scene(H, W, NV, seed=0, dataset="facescape", with_latent=False)
+    h, w = sc.latent_hw
+    latent = torch.randn((1, NV, 512, h, w), generator=torch.Generator(device=dev).manual_seed(3), device=dev)
+    wts = synth.make_mlp_weights(7, bias_scale=0.1)
+    m = model_from_scene(sc, wts, device=dev, latent=latent)
+    r = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G, white_bkgd=sc.white_bkgd)
+    rays_np = sc.target_rays()
+    rays = T(rays_np, dev)
+    assert rays.shape[1] == H * W
+    with torch.no_grad():
+        r.seed, r._calls = 11, 0
+        a = r(m, rays, want_weights=True)
+        r.seed, r._calls = 11, 0
+        b = r(m, rays)
+    assert torch.equal(a.fine.rgb, b.fine.rgb) and torch.equal(a.fine.depth, b.fine.depth)
+    rgb, depth = a.fine.rgb[0], a.fine.depth[0]
+    assert bool(torch.isfinite(rgb).all()) and float(rgb.min()) >= -1e-5 and float(rgb.max()) <= 1 + 1e-5
+    wsum = a.fine.weights[0].sum(-1)
+    assert float(a.fine.weights.min()) >= 0 and float(wsum.max()) <= 1 + 1e-5
+    near, far = rays[0, :, 6], rays[0, :, 7]
+    assert bool((depth <= far * wsum + 1e-4).all()) and bool((depth >= near * wsum - 1e-4).all())
+    assert float(wsum.mean()) > 0.3, "scene construction: most rays should hit the sphere"
+    # a sample of the same frame against the oracle (identical injected noise)
+    sel = np.linspace(0, H * W - 1, 384).astype(np.int64)
+    rs = np.ascontiguousarray(rays_np[:, sel])
+    noise = synth.make_noise(len(sel), NC, G, K, seed=5)
+    sc.latent = latent.cpu().numpy()
+    ref = Oracle(sc, wts).render(rs, NC, K, G, noise, white_bkgd=sc.white_bkgd)
+    with torch.no_grad():
+        out = r(m, T(rs, dev), noise=tuple(T(n, dev)[None] for n in noise))
+    agree(out.fine.rgb.cpu().numpy()[0], ref["rgb"], frac=0.99)
