@@ -61,6 +61,8 @@ SYMBOLS = {
     "diner_render_points_scratch_floats": (_I64, [_I64, _I32, _I32]),
     "diner_render_points": (C.c_int, [C.POINTER(DinerScene), _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
     "diner_composite": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
+    "diner_decode_depth_u16": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
+                                         _P, _P, _P, _P]),
     "diner_train_gemm": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I64,
                                    _I32, _P, _P, _I32, _I32, _P]),
     "diner_train_amax": (C.c_int, [_P, _I64, _P, _P]),

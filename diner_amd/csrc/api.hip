@@ -52,6 +52,8 @@ int launch_train_composite_bwd(const float *, const float *, const float *, cons
 int launch_gen_rays(const float *, const float *, const float *, const float *, int, int, int, float *, hipStream_t);
 int launch_depth2normal(const float *, const float *, int, int, int, float *, hipStream_t);
 int launch_pack_maps_from_depth(const float *, const float *, const float *, int, int, int, float *, hipStream_t);
+int launch_decode_depth(const unsigned short *, const unsigned short *, const unsigned short *, int64_t, int, int, int, float, float, float,
+                        float, float, float *, float *, float *, hipStream_t);
 int launch_linz_maps(const float *, int64_t, const float *, float *, hipStream_t);
 int launch_sampler(const DinerScene &, const float *, int64_t, const DinerSamplerCfg &, const float *, const float *,
                    const float *, const float *, uint64_t, float *, float *, float *, hipStream_t);
@@ -130,6 +132,17 @@ int diner_pack_maps_from_depth(const float *depths, const float *depths_std, con
     if (!depths || !depths_std || !intrinsics || !maps_out) return bad("pack_maps_from_depth: NULL pointer");
     if (N < 0 || N > 0x7fffffff || H <= 0 || W <= 0) return bad("pack_maps_from_depth: bad size");
     return launch_pack_maps_from_depth(depths, depths_std, intrinsics, (int)N, H, W, maps_out, (hipStream_t)stream);
+}
+
+int diner_decode_depth_u16(const uint16_t *depth, const uint16_t *conf, const uint16_t *mesh, int64_t N, int32_t H, int32_t W, int32_t stride,
+                           float mul0, float div, float mul1, float std_a, float std_b, float *depth_out, float *std_out, float *mask_out,
+                           void *stream)
+{
+    if (!depth || !conf || !depth_out || !std_out) return bad("decode_depth_u16: NULL pointer");
+    if (N < 0 || H <= 0 || W <= 0 || stride <= 0 || H % stride || W % stride) return bad("decode_depth_u16: bad size (stride must divide H and W)");
+    if (!(div != 0.0f)) return bad("decode_depth_u16: div must be non-zero");
+    return launch_decode_depth(depth, conf, mesh, N, H, W, stride, mul0, div, mul1, std_a, std_b, depth_out, std_out, mask_out,
+                               (hipStream_t)stream);
 }
 
 int diner_pack_latent(const float *latent_nchw, int64_t N, int32_t C, int32_t h, int32_t w, float *latent_out,

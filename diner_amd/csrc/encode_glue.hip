@@ -2,6 +2,8 @@
 // not per ray -- HBM-bound elementwise kernels, one thread per pixel:
 //   gen_rays      reference src/util/cam_geometry.py:36-79   (producer of the `rays` tensor)
 //   depth2normal  reference src/util/depth2normal.py:7-87    (normal maps inside PixelNeRF.encode)
+//   decode_depth  reference src/data/dtu.py:90-124,220-223, src/data/facescape.py:54-56,68-106,266
+//                 (TransMVSNet's uint16 depth / confidence planes -> depth [m], depth std)
 #include "common.hpp"
 
 namespace diner {
@@ -30,6 +32,37 @@ __global__ void gen_rays_kernel(const float *__restrict__ extr, const float *__r
     }
     o[6] = z_near[b];
     o[7] = z_far[b];
+}
+
+// One thread per OUTPUT pixel.  out(y, x) = in(y*stride, x*stride): torchvision's NEAREST resize for a downsample
+// of 1/stride (dtu.py:113-117).  depth = ((u16 * mul0) / div) * mul1 with one rounding per operation, the order of
+// dtu.py:104-105,119 (Facescape: div = mul1 = 1, facescape.py:80-91); std = a * conf + b with conf decoded the
+// same way (dtu.py:220-223, facescape.py:54-56,266).  `mesh` (optional, Facescape depth_type "merge",
+// facescape.py:96-104): mesh-rendered depth that wins wherever it is non-zero, with confidence 0.8.
+__global__ void decode_depth_kernel(const unsigned short *__restrict__ depth, const unsigned short *__restrict__ conf,
+                                    const unsigned short *__restrict__ mesh, int64_t N, int Hin, int Win, int stride, float mul0, float div,
+                                    float mul1, float std_a, float std_b, float *__restrict__ depth_out, float *__restrict__ std_out,
+                                    float *__restrict__ mask_out)
+{
+    const int Ho = Hin / stride, Wo = Win / stride;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * Ho * Wo) return;
+    const int64_t n = i / ((int64_t)Ho * Wo);
+    const int p = (int)(i - n * Ho * Wo), y = p / Wo, x = p - y * Wo;
+    const int64_t src = (n * Hin + (int64_t)y * stride) * Win + (int64_t)x * stride;
+    float d = (float)depth[src] * mul0, c = (float)conf[src] * mul0;
+    if (mesh) {
+        const float m = (float)mesh[src] * mul0, mc = m == 0.0f ? 0.0f : 0.8f;
+        d = (m == 0.0f && d != 0.0f) ? d : m;
+        c = (mc == 0.0f && c != 0.0f) ? c : mc;
+    }
+    d = d / div;
+    c = c / div;
+    if (mask_out) mask_out[i] = d > 0.0f ? 1.0f : 0.0f;   // dtu.py:118 (before the scene scale)
+    d = d * mul1;
+    c = c * mul1;
+    depth_out[i] = d;
+    std_out[i] = std_a * c + std_b;
 }
 
 // camera-space point of pixel (x,y) with replicate padding (depth2normal.py:22-33)
@@ -136,6 +169,17 @@ int launch_depth2normal(const float *dmap, const float *intr, int N, int H, int 
     if (total == 0) return DINER_OK;
     hipLaunchKernelGGL(depth2normal_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, dmap, intr, N, H, W, out);
     return check_launch("depth2normal_kernel");
+}
+
+int launch_decode_depth(const unsigned short *depth, const unsigned short *conf, const unsigned short *mesh, int64_t N, int Hin, int Win,
+                        int stride, float mul0, float div, float mul1, float std_a, float std_b, float *depth_out, float *std_out,
+                        float *mask_out, hipStream_t st)
+{
+    const int64_t n = N * (Hin / stride) * (Win / stride);
+    if (n == 0) return DINER_OK;
+    hipLaunchKernelGGL(decode_depth_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, depth, conf, mesh, N, Hin, Win, stride, mul0,
+                       div, mul1, std_a, std_b, depth_out, std_out, mask_out);
+    return check_launch("decode_depth_kernel");
 }
 
 }  // namespace diner

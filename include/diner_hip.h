@@ -104,6 +104,14 @@ int diner_pack_maps(const float *depths, const float *depths_std, const float *n
  * depths, depths_std [N,1,H,W], intrinsics [N,3,3] -> maps [N,H,W,8]; no NCHW normal tensor is materialised */
 int diner_pack_maps_from_depth(const float *depths, const float *depths_std, const float *intrinsics,
                                int64_t N, int32_t H, int32_t W, float *maps_out, void *stream);
+/* Upstream wire format: TransMVSNet's uint16 depth / confidence planes [N,H,W] ->
+ * depth_out, std_out (and mask_out = depth > 0, optional) [N,H/stride,W/stride] fp32, nearest-subsampled by
+ * `stride` (src/data/dtu.py:113-117):  depth = ((u16 * mul0) / div) * mul1,  std = std_a * conf + std_b with the
+ * confidence decoded like the depth (src/data/dtu.py:100-119,220-223; src/data/facescape.py:54-56,80-91,266).
+ * mesh (optional): Facescape's mesh-rendered depth for depth_type "merge" (src/data/facescape.py:96-104). */
+int diner_decode_depth_u16(const uint16_t *depth, const uint16_t *conf, const uint16_t *mesh, int64_t N, int32_t H,
+                           int32_t W, int32_t stride, float mul0, float div, float mul1, float std_a, float std_b,
+                           float *depth_out, float *std_out, float *mask_out, void *stream);
 /* latent [N,C,h,w] (NCHW, src/models/image_encoder.py:271) -> [N,h,w,C] with the channel order
  * the MLP kernel stages into LDS (C = 512) */
 int diner_pack_latent(const float *latent_nchw, int64_t N, int32_t C, int32_t h, int32_t w,
