@@ -377,6 +377,26 @@ class NeRFRendererDGS(torch.nn.Module):
                     self.stage_events.append(ev)
         return RenderOutput(fine=self._format_outputs(weights, rgb, depth, want_weights=want_weights))
 
+    @torch.no_grad()
+    def render_image(self, model, target_extrinsics, target_intrinsics, H, W, z_near, z_far, return_depth=False):
+        """The render half of ``DINER.predict_imgs_from_batch`` (reference src/models/diner.py:75-97) without the
+        ray-batch loop: rays of the whole target image(s) are generated on the GPU (``diner_gen_rays``,
+        src/util/cam_geometry.py:36-79) and rendered in ONE launch per stage (the native mode: no 4096-ray chunks,
+        no ``torch.cat``), output in the reference's image layout.
+        :param target_extrinsics: [SB,4,4] world->cam;  target_intrinsics: [SB,3,3];  z_near, z_far: [SB] or scalars
+        :return: rgb [SB,3,H,W] (, depth [SB,1,H,W])"""
+        from . import glue
+        SB = target_extrinsics.shape[0]
+        dev = target_extrinsics.device
+        zn = torch.as_tensor(z_near, dtype=torch.float32, device=dev).expand(SB)
+        zf = torch.as_tensor(z_far, dtype=torch.float32, device=dev).expand(SB)
+        rays = glue.gen_rays(target_extrinsics, target_intrinsics, W, H, zn, zf).view(SB, H * W, 8)
+        out = self.forward(model, rays).fine
+        rgb = out.rgb.view(SB, H, W, 3).permute(0, 3, 1, 2)
+        if return_depth:
+            return rgb, out.depth.view(SB, H, W, 1).permute(0, 3, 1, 2)
+        return rgb
+
     def _forward_train(self, model, rays, want_weights, noise=None, z_samples=None):
         """Training path (reference DINER.calc_losses, src/models/diner.py:217-290): sampler under no_grad
         (src/models/nerf_renderer.py:65), then the differentiable point evaluation + compositing of

@@ -72,3 +72,30 @@ def test_fused_depth2normal_packing_equals_two_step(glue):
                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), "diner_pack_maps")
     torch.cuda.synchronize()
     assert torch.equal(torch.nan_to_num(fused), torch.nan_to_num(two))
+
+
+@pytest.mark.gpu
+def test_render_image_equals_chunked_forward():
+    """``render_image`` (rays generated on the GPU, one launch) against the reference's flow of
+    predict_imgs_from_batch (src/models/diner.py:75-97): gen_rays -> forward on the ray tensor -> view/permute."""
+    import torch
+    from diner_amd import NeRFRendererDGS, glue, synth
+    from diner_amd.model_stub import model_from_scene
+    dev = torch.device("cuda:0")
+    sc = synth.make_scene(24, 32, 3, seed=5, feature_padding=4)
+    m = model_from_scene(sc, synth.make_mlp_weights(6, bias_scale=0.1), device=dev)
+    r = NeRFRendererDGS(n_samples=16, n_depth_candidates=128, n_gaussian=5, white_bkgd=sc.white_bkgd)
+    H, W = 20, 28
+    E = torch.from_numpy(np.ascontiguousarray(sc.target_extrinsics, dtype=np.float32))[None].to(dev)
+    Kt = torch.tensor([[[1.2 * W, 0, W / 2], [0, 1.2 * W, H / 2], [0, 0, 1]]], dtype=torch.float32, device=dev)
+    near, far = float(sc.near), float(sc.far)
+    r.seed, r._calls = 3, 0
+    rgb, depth = r.render_image(m, E, Kt, H, W, near, far, return_depth=True)
+    assert tuple(rgb.shape) == (1, 3, H, W) and tuple(depth.shape) == (1, 1, H, W)
+    rays = glue.gen_rays(E, Kt, W, H, torch.tensor([near], device=dev), torch.tensor([far], device=dev)).view(1, H * W, 8)
+    r.seed, r._calls = 3, 0
+    with torch.no_grad():
+        ref = r(m, rays).fine
+    assert torch.equal(rgb, ref.rgb.view(1, H, W, 3).permute(0, 3, 1, 2))
+    assert torch.equal(depth, ref.depth.view(1, H, W, 1).permute(0, 3, 1, 2))
+    assert float(rgb.min()) >= -1e-5 and float(rgb.max()) <= 1 + 1e-5
