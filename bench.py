@@ -12,8 +12,9 @@ the same scene (weak scaling: rays are independent, maps/weights replicated) and
 
 Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
   roofline      dominant kernel (fused point/MLP kernel, MFMA-bound): algorithmic FLOP per launch
-                / its average duration from HIP events over the timed region, vs the dense fp32
-                MFMA peak; plus `sampling_integration` (HBM-bound kernels, logical bytes).
+                / its average duration from HIP events over the timed region, vs the dense MFMA
+                peak of the arithmetic in use (fp16 for the default f16x3 mode, fp32 for
+                --precision fp32); plus `sampling_integration` (HBM-bound kernels, logical bytes).
   cpu_baseline  the CPU oracle (a C port of the reference algorithm, oracle/) timed on the host
                 cores on a bounded sample of the same workload (rank 0, N=1 only).
 """
@@ -26,8 +27,11 @@ import sys
 import time
 from pathlib import Path
 
-import numpy as np
-import torch
+# the hosts of this pool only support dmabuf IPC (RCCL / cross-process device memory): must be set before HIP starts
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
 
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
