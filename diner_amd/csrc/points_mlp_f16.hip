@@ -232,6 +232,10 @@ __device__ __forceinline__ void store_relu(const f32x16 (&acc)[CT][2], _Float16 
 }
 
 constexpr int SLAB_FLOATS = TILE_P * HID;  // one view's x of one tile (128 KiB)
+// rounds between two pacing points (power of two).  Kernel time in ms, same binary otherwise -- box A: 1 -> 1416, 2 -> 1405,
+// 4 -> 1404; box B: 1 -> 1421, 4 -> 1412, 8 -> 1414, 16 -> 1423, 64 -> 1549.  Re-syncing every tile makes every round as slow
+// as its slowest workgroup; hardly ever re-syncing loses the shared L2 hits on the weight stream.
+constexpr int PACE_EVERY = 4;
 constexpr int SYNC_WORDS = 256;            // head of the scratch: 8 pacing counters, one per 128-byte line
 
 struct Tap {
@@ -296,7 +300,7 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
         slot = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + b / 8;
     }
     // Pacing (speed only, no data is exchanged): the workgroups that share an XCD (equal blockIdx % 8) start
-    // every tile together.  They all stream the same 1 MiB weight layers in the same order; kept in step, one
+    // every PACE_EVERY-th tile together.  They all stream the same 1 MiB weight layers in the same order; kept in step, one
     // fetch from the Infinity Cache serves the whole XCD through its L2, while drifting apart they each
     // miss (measured: L2 hit rate 56 % unpaced).  A monotonic counter per group, bounded polling: a
     // workgroup that times out stops pacing for the rest of the launch and simply goes on, so residency or
@@ -308,10 +312,10 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
     bool pace_on = true;
     volatile int *pace_flag = (volatile int *)(lds + 2 * UNITS + TILE_P * 2 + BIAS_FLOATS / 4);  // one LDS word
     for (int64_t tile = slot; tile < tiles; tile += gridDim.x, ++round) {
-        if (pace_on && round < full_rounds && group > 1) {
+        if (pace_on && round < full_rounds && group > 1 && (round & (PACE_EVERY - 1)) == 0) {
             if (tid == 0) {
                 __hip_atomic_fetch_add(pace, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const unsigned int want = (unsigned int)(round + 1) * group;
+                const unsigned int want = (unsigned int)(round / PACE_EVERY + 1) * group;
                 int spin = 0;
                 for (; spin < 4000; ++spin) {
                     if (__hip_atomic_load(pace, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
