@@ -19,7 +19,7 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 @pytest.mark.skipif(not Path(HIPCC).exists(), reason="hipcc not available")
 def test_f16_gemm_loops_have_no_spill_code(tmp_path):
     asm = tmp_path / "points_mlp_f16.s"
-    subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-S", "--cuda-device-only",
+    subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-unroll-loops", "-S", "--cuda-device-only",
                     "-o", str(asm), str(ROOT / "diner_amd/csrc/points_mlp_f16.hip")], check=True, capture_output=True, timeout=900)
     lines = asm.read_text().split("\n")
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN5diner5f16x321points_mlp_f16_kernelILb0E\S+:", l)]
