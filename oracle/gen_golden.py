@@ -35,6 +35,9 @@ CASES = {
                              K=64, NC=1000, G=24, ray_stride=32, focal_scale=1.0, wseed=7, bias_scale=0.1, nseed=8),
     "g3_nv3_k40_wide": dict(scene=dict(H=32, W=32, NV=3, seed=9, dataset="facescape", feature_padding=4),
                             K=40, NC=1000, G=15, ray_stride=8, focal_scale=0.45, wseed=10, bias_scale=0.1, nseed=11),
+    # the headline renderer parameters of BASELINE.json (K=128, G=48, NC=1000, 4 views, Facescape near/far, padding 32)
+    "g4_nv4_k128_headline": dict(scene=dict(H=64, W=64, NV=4, seed=12, dataset="facescape", feature_padding=32),
+                                 K=128, NC=1000, G=48, ray_stride=61, focal_scale=1.0, wseed=7, bias_scale=0.1, nseed=14),
 }
 N_FULL_INPUT_POINTS = 16   # points whose full 567-vector is stored
 N_TAIL_INPUT_POINTS = 512  # points whose 55 non-latent inputs are stored
@@ -146,13 +149,17 @@ def main():
     from oracle import ref_harness as rh
     out_dir = ROOT / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
-    gen_glue(out_dir)
-    if "--glue-only" in sys.argv:
-        return
-    gen_train(out_dir)
-    if "--train-only" in sys.argv:
-        return
+    if not any(a.startswith("--case=") for a in sys.argv):
+        gen_glue(out_dir)
+        if "--glue-only" in sys.argv:
+            return
+        gen_train(out_dir)
+        if "--train-only" in sys.argv:
+            return
+    only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--case=")]   # regenerate selected cases only
     for name, cfg in CASES.items():
+        if only and name not in only:
+            continue
         t0 = time.time()
         sc, w, rays, noise = case_inputs(cfg)
         nerf = rh.build_model(sc, w)

@@ -35,6 +35,17 @@ class GoldenCase:
     def __getitem__(self, k):
         return self.data[k]
 
+    @property
+    def firm_rays(self):
+        """Rays none of whose candidates has a likelihood of a few 1e-8 in the reference: |erf(a) - erf(b)| / 2 is
+        0, 3e-8 or 6e-8 there depending on the last ulp of the erf implementation (Sleef in ATen, libm in the oracle,
+        the GPU math library in the kernels), and a candidate that is "non-zero" is kept as a sample where a zero one
+        is replaced by a uniform fill-up sample.  With K - G = 80 slots (headline parameters, g4) most rays that hit
+        the surface own such a candidate; with 10-40 slots (g0-g3) few do.  Set-equality assertions are made on the
+        firm rays; on the others the differing candidates must all be of that kind (soft_shortlist_mismatch)."""
+        L = self.data["pt_likelihood"]
+        return ~((L > 0) & (L <= 1.2e-7)).any(-1)
+
 
 _cache = {}
 
