@@ -38,6 +38,9 @@ CASES = {
     # the headline renderer parameters of BASELINE.json (K=128, G=48, NC=1000, 4 views, Facescape near/far, padding 32)
     "g4_nv4_k128_headline": dict(scene=dict(H=64, W=64, NV=4, seed=12, dataset="facescape", feature_padding=32),
                                  K=128, NC=1000, G=48, ray_stride=61, focal_scale=1.0, wseed=7, bias_scale=0.1, nseed=14),
+    # BASELINE.json's stress configuration: 8 source views, 256 samples per ray (G = 96)
+    "g5_nv8_k256_stress": dict(scene=dict(H=48, W=48, NV=8, seed=15, dataset="facescape", feature_padding=32),
+                               K=256, NC=1000, G=96, ray_stride=53, focal_scale=1.0, wseed=16, bias_scale=0.1, nseed=17),
 }
 N_FULL_INPUT_POINTS = 16   # points whose full 567-vector is stored
 N_TAIL_INPUT_POINTS = 512  # points whose 55 non-latent inputs are stored
