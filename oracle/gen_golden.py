@@ -106,6 +106,17 @@ TRAIN_CASE = dict(scene=dict(H=16, W=16, NV=2, seed=12, dataset="facescape", fea
                   ray_stride=8, focal_scale=1.0, wseed=13, bias_scale=0.1, nseed=14, cseed=15)
 
 
+# second training case: DTU near/far and black background (white_bkgd False), 3 views, and a cotangent on the
+# compositing weights as well (the reference's losses may use them, src/models/diner.py:262-290)
+TRAIN_CASE_DTU = dict(scene=dict(H=20, W=16, NV=3, seed=21, dataset="dtu", feature_padding=4), K=12, NC=96, G=4,
+                      ray_stride=9, focal_scale=1.0, wseed=7, bias_scale=0.1, nseed=23, cseed=24, weights_cotangent=True)
+TRAIN_CASES = {"train": TRAIN_CASE, "train_dtu": TRAIN_CASE_DTU}
+
+
+def weights_cotangent(NR, K, cseed):
+    return np.random.RandomState(cseed + 1000).standard_normal((1, NR, K)).astype(np.float32)
+
+
 def train_cotangents(NR, cseed):
     rs = np.random.RandomState(cseed)
     return rs.standard_normal((1, NR, 3)).astype(np.float32), rs.standard_normal((1, NR)).astype(np.float32)
@@ -116,12 +127,12 @@ def grad_probe_indices(shape, n=64, seed=99):
     return rs.randint(0, int(np.prod(shape)), size=min(n, int(np.prod(shape))))
 
 
-def gen_train(out_dir):
-    """Gradients of L = <c_rgb, rgb> + <c_depth, depth> w.r.t. every MLP parameter and the latent, from the
-    reference's own autograd (composite + PixelNeRF.forward + ResnetFC on the reference's sorted samples)."""
+def gen_train(out_dir, name="train"):
+    """Gradients of L = <c_rgb, rgb> + <c_depth, depth> (+ <c_w, weights>) w.r.t. every MLP parameter and the latent,
+    from the reference's own autograd (composite + PixelNeRF.forward + ResnetFC on the reference's sorted samples)."""
     import torch
     from oracle import ref_harness as rh
-    cfg = TRAIN_CASE
+    cfg = TRAIN_CASES[name]
     sc, w, rays, noise = case_inputs(cfg)
     nerf = rh.build_model(sc, w)
     ref = rh.run_reference(nerf, rays, cfg["K"], cfg["NC"], cfg["G"], noise, white_bkgd=sc.white_bkgd, want_internals=False)
@@ -134,17 +145,19 @@ def gen_train(out_dir):
     weights, rgb, depth = rend.composite(nerf, torch.from_numpy(rays), z)
     c_rgb, c_depth = train_cotangents(rays.shape[1], cfg["cseed"])
     loss = (rgb * torch.from_numpy(c_rgb)).sum() + (depth * torch.from_numpy(c_depth)).sum()
+    if cfg.get("weights_cotangent"):
+        loss = loss + (weights * torch.from_numpy(weights_cotangent(rays.shape[1], cfg["K"], cfg["cseed"]))).sum()
     loss.backward()
     fixture = dict(config=json.dumps(cfg), z_fill=ref["z_fill"], rgb=rgb.detach().numpy(), depth=depth.detach().numpy(),
                    latent_grad=nerf.encoder.latent.grad.numpy())
-    for name, p in nerf.mlp_fine.named_parameters():
+    for pname, p in nerf.mlp_fine.named_parameters():
         gnp = p.grad.numpy()
         idx = grad_probe_indices(gnp.shape)
-        fixture[f"g_sum/{name}"] = np.float64(gnp.astype(np.float64).sum())
-        fixture[f"g_norm/{name}"] = np.float64(np.sqrt((gnp.astype(np.float64) ** 2).sum()))
-        fixture[f"g_probe/{name}"] = gnp.reshape(-1)[idx]
-    np.savez_compressed(out_dir / "train.npz", **fixture)
-    print(f"train: NR={rays.shape[1]} |latent_grad|={np.abs(fixture['latent_grad']).max():.3e} "
+        fixture[f"g_sum/{pname}"] = np.float64(gnp.astype(np.float64).sum())
+        fixture[f"g_norm/{pname}"] = np.float64(np.sqrt((gnp.astype(np.float64) ** 2).sum()))
+        fixture[f"g_probe/{pname}"] = gnp.reshape(-1)[idx]
+    np.savez_compressed(out_dir / f"{name}.npz", **fixture)
+    print(f"{name}: NR={rays.shape[1]} |latent_grad|={np.abs(fixture['latent_grad']).max():.3e} "
           f"|g lin_out.w|={fixture['g_norm/lin_out.weight']:.3e} |g lin_in.w|={fixture['g_norm/lin_in.weight']:.3e}")
 
 
@@ -156,7 +169,11 @@ def main():
         gen_glue(out_dir)
         if "--glue-only" in sys.argv:
             return
-        gen_train(out_dir)
+        if "--train-dtu-only" in sys.argv:   # adds the second training case without touching the first
+            gen_train(out_dir, "train_dtu")
+            return
+        for tname in TRAIN_CASES:
+            gen_train(out_dir, tname)
         if "--train-only" in sys.argv:
             return
     only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--case=")]   # regenerate selected cases only
