@@ -53,6 +53,10 @@ CONFIGS = {
     "cfg3": dict(H=512, W=512, NV=4, K=128, G=48, NC=1000, dataset="facescape",
                  desc="cfg3: Facescape-like head, 512x512 target, 4 src views 512x512, K=128 (G=48), NC=1000, "
                       "depth-guided sampling on"),
+    # BASELINE.json configs[4] (stress: 8 source views, 256 samples/ray) at a quarter of its image size so that a frame
+    # costs about as much as a cfg3 frame; not the headline, a scaling data point
+    "cfg5s": dict(H=256, W=256, NV=8, K=256, G=96, NC=1000, dataset="facescape",
+                  desc="cfg5s: Facescape-like head, 256x256 target, 8 src views 256x256, K=256 (G=96), NC=1000"),
     # small plumbing config for quick checks
     "tiny": dict(H=64, W=64, NV=4, K=64, G=24, NC=1000, dataset="facescape",
                  desc="tiny: 64x64 target, 4 src views, K=64 (plumbing only)"),
