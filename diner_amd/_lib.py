@@ -70,7 +70,7 @@ SYMBOLS = {
     "diner_train_split_panel": (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _P]),
     "diner_train_gemm_panel": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P, _I32, _I32, _P]),
     "diner_train_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),
-    "diner_train_point_inputs": (C.c_int, [C.POINTER(DinerScene), _P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
+    "diner_train_point_inputs": (C.c_int, [C.POINTER(DinerScene), _P, _I32, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
     "diner_train_bilinear_scatter": (C.c_int, [_P, _P, _I64, _I32, _I32, _I32, _I32, _I32, _P, _P]),
     "diner_train_nhwc_to_nchw": (C.c_int, [_P, _I64, _I32, _I32, _I32, _P, _P]),
     "diner_train_view_mean": (C.c_int, [_P, _I64, _I32, _P, _I32, _P]),

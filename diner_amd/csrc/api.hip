@@ -41,7 +41,7 @@ int launch_train_split_panel(const float *, int, int64_t, int, int, void *, void
 int launch_train_gemm_panel(const float *, int64_t, const void *, const void *, const float *, const float *, int64_t, const float *,
                             int64_t, float *, int64_t, int64_t, int, int, const unsigned int *, int, int, hipStream_t);
 int launch_train_colsum(const float *, int64_t, int, int64_t, float *, hipStream_t);
-int launch_train_point_inputs(const DinerScene &, const float *, const float *, const float *, int64_t, int, int, float *, float *,
+int launch_train_point_inputs(const DinerScene &, const float *, int, const float *, const float *, int64_t, int, int, float *, float *,
                               float *, hipStream_t);
 int launch_train_bilinear_scatter(const float *, const float *, int64_t, int, int, int, int, int, float *, hipStream_t);
 int launch_train_view_mean(const float *, int64_t, int, float *, int, hipStream_t);
@@ -282,14 +282,14 @@ int diner_train_colsum(const float *dY, int64_t M, int32_t N, int64_t ld, float 
     return launch_train_colsum(dY, M, N, ld, db, (hipStream_t)stream);
 }
 
-int diner_train_point_inputs(const DinerScene *scene, const float *latent_nchw, const float *rays, const float *z, int64_t NR,
-                             int32_t K, int32_t sb, float *in56, float *zlat, float *taps, void *stream)
+int diner_train_point_inputs(const DinerScene *scene, const float *latent, int32_t latent_is_nhwc, const float *rays, const float *z,
+                             int64_t NR, int32_t K, int32_t sb, float *in56, float *zlat, float *taps, void *stream)
 {
     int rc;
     if ((rc = check_scene(scene, false))) return rc;
-    if (!latent_nchw || !rays || !z || !in56 || !zlat || !taps) return bad("train_point_inputs: NULL pointer");
+    if (!latent || !rays || !z || !in56 || !zlat || !taps) return bad("train_point_inputs: NULL pointer");
     if (scene->C != DINER_D_LATENT || scene->h <= 0 || scene->w <= 0 || sb < 0 || sb >= scene->SB) return bad("train_point_inputs: bad scene");
-    return launch_train_point_inputs(*scene, latent_nchw, rays, z, NR, K, sb, in56, zlat, taps, (hipStream_t)stream);
+    return launch_train_point_inputs(*scene, latent, latent_is_nhwc, rays, z, NR, K, sb, in56, zlat, taps, (hipStream_t)stream);
 }
 
 int diner_train_bilinear_scatter(const float *dz, const float *taps, int64_t P, int32_t C, int32_t h, int32_t w, int32_t NV, int32_t sb,

@@ -670,6 +670,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float *__restrict__ d
 // ---- per-(view, point) MLP inputs: in55 (padded to 56), bilinear latent z, and the footprint ------------------
 // rows are view-major: row = v*P + p.  latent is the reference's NCHW tensor [NV,C,h,w] (its gradient has
 // that layout too).  taps_out [R,8] = 4 texel indices (y*w+x, as int bits) + 4 weights.
+template <bool NHWC>
 __global__ __launch_bounds__(64) void point_inputs_kernel(DinerScene s, const float *__restrict__ latent_nchw,
                                                           const float *__restrict__ rays, const float *__restrict__ zsamp,
                                                           int64_t NR, int K, int sb, float *__restrict__ in56,
@@ -723,8 +724,11 @@ __global__ __launch_bounds__(64) void point_inputs_kernel(DinerScene s, const fl
     const int64_t plane = (int64_t)s.h * s.w;
     const float *lat = latent_nchw + ((int64_t)sb * s.NV + v) * s.C * plane;
     for (int ch = lane; ch < s.C; ch += 64) {
-        const float *pl = lat + ch * plane;
-        zlat[row * s.C + ch] = __builtin_fmaf(pl[o[3]], wt[3], __builtin_fmaf(pl[o[2]], wt[2], __builtin_fmaf(pl[o[1]], wt[1], pl[o[0]] * wt[0])));
+        float t[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)  // NHWC (diner_pack_latent): a wave reads 256 contiguous bytes of a texel; NCHW: 64 planes
+            t[i] = NHWC ? lat[(int64_t)o[i] * s.C + ch] : lat[ch * plane + o[i]];
+        zlat[row * s.C + ch] = __builtin_fmaf(t[3], wt[3], __builtin_fmaf(t[2], wt[2], __builtin_fmaf(t[1], wt[1], t[0] * wt[0])));
     }
 }
 
@@ -899,12 +903,13 @@ int launch_train_colsum(const float *dY, int64_t M, int N, int64_t ld, float *db
     return check_launch("train::colsum_kernel");
 }
 
-int launch_train_point_inputs(const DinerScene &s, const float *latent_nchw, const float *rays, const float *z, int64_t NR, int K,
+int launch_train_point_inputs(const DinerScene &s, const float *latent, int nhwc, const float *rays, const float *z, int64_t NR, int K,
                               int sb, float *in56, float *zlat, float *taps, hipStream_t st)
 {
     const int64_t R = NR * (int64_t)K * s.NV;
     if (R == 0) return DINER_OK;
-    hipLaunchKernelGGL(point_inputs_kernel, dim3((unsigned)R), dim3(64), 0, st, s, latent_nchw, rays, z, NR, K, sb, in56, zlat, taps);
+    if (nhwc) hipLaunchKernelGGL((point_inputs_kernel<true>), dim3((unsigned)R), dim3(64), 0, st, s, latent, rays, z, NR, K, sb, in56, zlat, taps);
+    else hipLaunchKernelGGL((point_inputs_kernel<false>), dim3((unsigned)R), dim3(64), 0, st, s, latent, rays, z, NR, K, sb, in56, zlat, taps);
     return check_launch("train::point_inputs_kernel");
 }
 

@@ -137,6 +137,9 @@ class _RenderFn(torch.autograd.Function):
         R = NV * P
         f = lambda *s: torch.empty(s, dtype=torch.float32, device=dev)
         lat = latent.detach().to(torch.float32).contiguous()
+        SBl, NVl, Cl, hl, wl = lat.shape
+        lat_nhwc = torch.empty((SBl, NVl, hl, wl, Cl), dtype=torch.float32, device=dev)   # coalesced texel reads for the gather
+        check(L.diner_pack_latent(_p(lat), SBl * NVl, Cl, hl, wl, _p(lat_nhwc), st), "diner_pack_latent")
         prm = [p.detach().to(torch.float32).contiguous() for p in params]
         w_in56 = torch.zeros((HID, 56), dtype=torch.float32, device=dev)
         w_in56[:, :55] = prm[0]
@@ -147,7 +150,7 @@ class _RenderFn(torch.autograd.Function):
         wp[0] = split_panel(w_in56, False, prec)
         for sb in range(SB):
             in56, zl, taps = f(R, 56), f(R, HID), f(R, 8)
-            check(L.diner_train_point_inputs(C.byref(scene), _p(lat), _p(rays), _p(z), NR, K, sb, _p(in56), _p(zl), _p(taps), st),
+            check(L.diner_train_point_inputs(C.byref(scene), _p(lat_nhwc), 1, _p(rays), _p(z), NR, K, sb, _p(in56), _p(zl), _p(taps), st),
                   "diner_train_point_inputs")
             x = f(R, HID)
             linear_fwd(in56, w_in56, prm[1], x, prec=prec, panel=wp[0])                          # resnetfc.py:139

@@ -223,9 +223,12 @@ int diner_train_gemm_panel(const float *A, int64_t sam, const void *Bhi, const v
 /* db[n] += sum_m dY[m*ld + n] */
 int diner_train_colsum(const float *dY, int64_t M, int32_t N, int64_t ld, float *db, void *stream);
 /* per (view, point) row = v*P + p of scene sb: in56 [R,56] (55 inputs of pixelnerf.py:128 + 0), z [R,512]
- * (bilinear latent, image_encoder.py:97-127) from the NCHW latent, taps [R,8] (4 texel indices, 4 weights) */
-int diner_train_point_inputs(const DinerScene *scene, const float *latent_nchw, const float *rays, const float *z,
-                             int64_t NR, int32_t K, int32_t sb, float *in56, float *zlat, float *taps, void *stream);
+ * (bilinear latent, image_encoder.py:97-127), taps [R,8] (4 texel indices, 4 weights).  latent: the reference's
+ * NCHW tensor [SB,NV,512,h,w], or (latent_is_nhwc) its diner_pack_latent copy [SB,NV,h,w,512] -- same values, a
+ * wave then reads whole 256-byte pieces of a texel instead of 64 planes */
+int diner_train_point_inputs(const DinerScene *scene, const float *latent, int32_t latent_is_nhwc, const float *rays,
+                             const float *z, int64_t NR, int32_t K, int32_t sb, float *in56, float *zlat, float *taps,
+                             void *stream);
 /* dlatent_nhwc[sb][v][texel][ch] += dz[row][ch] * weight (float atomics on 256-byte contiguous rows; the
  * caller zeroes the [SB,NV,h,w,C] buffer), then diner_train_nhwc_to_nchw gives encoder.latent's layout */
 int diner_train_bilinear_scatter(const float *dz, const float *taps, int64_t P, int32_t C, int32_t h, int32_t w,
