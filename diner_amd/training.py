@@ -232,7 +232,7 @@ class _RenderFn(torch.autograd.Function):
                 d_x = d_prev
             d_xv = f(R, HID)
             check(L.diner_train_view_mean(_p(d_x), P * HID, NV, _p(d_xv), 1, st), "diner_train_view_mean(bwd)")
-            d_zl = torch.zeros((R, HID), dtype=torch.float32, device=dev)
+            d_zl = f(R, HID)          # written by the first (b = 2) lin_z backward, accumulated by the other two
             for b in (2, 1, 0):                                                   # per-view blocks, reversed
                 d_net = f(R, HID)
                 a_xv = colsum_amax(d_xv, g[11 + 4 * b], prec)
@@ -244,7 +244,7 @@ class _RenderFn(torch.autograd.Function):
                 linear_bwd_w(d_net, xs[b], g[8 + 4 * b], None, relu_x=True, prec=prec, amax=a_net)
                 a_xs = colsum_amax(d_xs, g[3 + 2 * b], prec)
                 linear_bwd_w(d_xs, zl, g[2 + 2 * b], None, prec=prec, amax=a_xs)          # lin_z[b]
-                linear_bwd_x(d_xs, prm[2 + 2 * b], None, d_zl, addend=d_zl, prec=prec, amax=a_xs, panel=wt[2 + 2 * b])
+                linear_bwd_x(d_xs, prm[2 + 2 * b], None, d_zl, addend=None if b == 2 else d_zl, prec=prec, amax=a_xs, panel=wt[2 + 2 * b])
                 d_xv = d_xs
             linear_bwd_w(d_xv, in56, g_in56, None, prec=prec, amax=a_xs)           # lin_in (its d_xv is lin_z[0]'s d_xs)
             check(L.diner_train_bilinear_scatter(_p(d_zl), _p(taps), P, HID, scene.h, scene.w, NV, sb, _p(d_lat_nhwc), st),
