@@ -538,10 +538,14 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelArgs g)
     store_b(T[0], stb, tid);
     __syncthreads();
 #define DINER_PANEL_STEP(SL)                                                                                     \
-    {                                                                                                            \
-        if (t + 1 < steps) load_b(stb, g, n0, (t + 1) * PK, tid);                                                \
-        if (t + 2 < steps) load_a(sta[SL], g, m0, (t + 2) * PK, tid);                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                       \
+    {   /* ONE basic block per step (loads unconditional: past the end they re-read the last tile / load zeros),     \
+           so that the scheduler can be told to spread the step's 6 global loads and the split of tile t+1 (VALU)     \
+           BETWEEN the MFMAs: a wave issues in order, and after the barrier all 8 waves otherwise queue their loads   \
+           at the texture-address unit at once (48 KiB per step = 768 clocks at 64 B/clk) before the first MFMA.      \
+           Same-box A/B: 1.370 -> 1.288 ms per forward GEMM */                                                        \
+        const int tb_ = t + 1 < steps ? t + 1 : steps - 1, ta_ = t + 2;                                          \
+        load_b(stb, g, n0, tb_ * PK, tid);                                                                       \
+        load_a(sta[SL], g, m0, ta_ * PK, tid);                                                                   \
         {                                                                                                        \
             const h8 *Ahi = T[SL], *Alo = T[SL] + A_UNITS, *Bhi = T[SL] + 2 * A_UNITS, *Blo = Bhi + B_UNITS;     \
             _Pragma("unroll") for (int ks = 0; ks < PK / 16; ++ks) {                                             \
@@ -560,11 +564,17 @@ __global__ __launch_bounds__(512) void gemm_panel_kernel(PanelArgs g)
                     }                                                                                            \
             }                                                                                                    \
         }                                                                                                        \
-        /* no scheduling fence here: the split of A(t+1) (its loads are a step old) may slide between the MFMAs */ \
-        if (t + 1 < steps) {                                                                                     \
-            store_a(T[1 - SL], sta[1 - SL], fa, sa, tid);                                                        \
-            store_b(T[1 - SL], stb, tid);                                                                        \
+        store_a(T[1 - SL], sta[1 - SL], fa, sa, tid);                                                            \
+        /* sched_group_barrier masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x002 VALU */                  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  /* fragments of the first k-step */                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) {                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+            if (i_ < 12 && (i_ & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     \
+            if (i_ < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                                                   \
         }                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        store_b(T[1 - SL], stb, tid);                                                                            \
         __syncthreads();                                                                                         \
     }
     for (int t = 0; t < steps; ++t) {
