@@ -746,22 +746,51 @@ __global__ __launch_bounds__(64) void point_inputs_kernel(DinerScene s, const fl
 // The target is NHWC on purpose: a wave's 64 channels of one texel are 256 contiguous bytes, the shape in which
 // float atomics run at the full memory-side rate (64 lanes in 64 different rows are ~17x slower: scattering
 // straight into the reference's NCHW layout took 82 ms per step, this + the transpose below 5 ms).
+// One wave walks SCATTER_RUN consecutive rows (= consecutive samples of a ray in one view, whose 2x2 footprints move by a
+// fraction of a texel per sample): contributions are summed in registers while the four texel indices stay the same
+// and flushed with one atomic per tap when they change -- float atomics run at a fixed memory-side rate (~1.3 TB/s of
+// added bytes), so fewer of them is the only lever.
+constexpr int SCATTER_RUN = 16;
 __global__ __launch_bounds__(64) void bilinear_scatter_kernel(const float *__restrict__ dz, const float *__restrict__ taps,
                                                               int64_t P, int C, int h, int w, int NV, int sb,
                                                               float *__restrict__ dlatent_nhwc)
 {
-    const int64_t row = blockIdx.x;
-    const int v = (int)(row / P), lane = threadIdx.x;
-    float *lat = dlatent_nhwc + ((int64_t)sb * NV + v) * h * w * C;
-    int o[4];
-    float wt[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { o[i] = __float_as_int(taps[row * 8 + i]); wt[i] = taps[row * 8 + 4 + i]; }
+    const int64_t R = P * NV, row0 = (int64_t)blockIdx.x * SCATTER_RUN;
+    const int64_t row1 = row0 + SCATTER_RUN < R ? row0 + SCATTER_RUN : R;
+    const int lane = threadIdx.x;
     for (int ch = lane; ch < C; ch += 64) {
-        const float g = dz[row * C + ch];
+        int cur[4] = {-1, -1, -1, -1};
+        int64_t cur_v = -1;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        bool used[4] = {false, false, false, false};
+        for (int64_t row = row0; row < row1; ++row) {
+            const int64_t v = row / P;
+            int o[4];
+            float wt[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            if (wt[i] != 0.0f) atomicAdd(lat + (int64_t)o[i] * C + ch, g * wt[i]);
+            for (int i = 0; i < 4; ++i) { o[i] = __float_as_int(taps[row * 8 + i]); wt[i] = taps[row * 8 + 4 + i]; }
+            if (v != cur_v || o[0] != cur[0] || o[1] != cur[1] || o[2] != cur[2] || o[3] != cur[3]) {  // wave-uniform
+                if (cur_v >= 0) {
+                    float *lat = dlatent_nhwc + ((int64_t)sb * NV + cur_v) * h * w * C;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (used[i]) atomicAdd(lat + (int64_t)cur[i] * C + ch, acc[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { cur[i] = o[i]; acc[i] = 0.f; used[i] = false; }
+                cur_v = v;
+            }
+            const float g = dz[row * C + ch];
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (wt[i] != 0.0f) { acc[i] += g * wt[i]; used[i] = true; }
+        }
+        if (cur_v >= 0) {
+            float *lat = dlatent_nhwc + ((int64_t)sb * NV + cur_v) * h * w * C;
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (used[i]) atomicAdd(lat + (int64_t)cur[i] * C + ch, acc[i]);
+        }
     }
 }
 
@@ -927,7 +956,8 @@ int launch_train_bilinear_scatter(const float *dz, const float *taps, int64_t P,
                                   float *dlatent, hipStream_t st)
 {
     if (P * NV == 0) return DINER_OK;
-    hipLaunchKernelGGL(bilinear_scatter_kernel, dim3((unsigned)(P * NV)), dim3(64), 0, st, dz, taps, P, C, h, w, NV, sb, dlatent);
+    hipLaunchKernelGGL(bilinear_scatter_kernel, dim3((unsigned)((P * NV + SCATTER_RUN - 1) / SCATTER_RUN)), dim3(64), 0, st, dz, taps, P, C, h, w, NV,
+                       sb, dlatent);
     return check_launch("train::bilinear_scatter_kernel");
 }
 
