@@ -1,14 +1,21 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X-native DINER render path: rendered rays/s.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3] [--scaling weak|strong]
 
 A *step* renders one full target frame per GPU through the product path
 (`diner_amd.NeRFRendererDGS.forward`: depth-guided sampler -> fused projection/gather/fusion-MLP
-kernel -> alpha compositing), with maps, latent and weights already resident in HBM.  With N > 1
-(launched by torch.distributed.run, one rank per GPU) every rank renders its own target pose of
-the same scene (weak scaling: rays are independent, maps/weights replicated) and the rendered
-[rays,4] tiles are all-gathered over RCCL inside the timed region.
+kernel -> alpha compositing), with maps, latent and weights already resident in HBM.
+
+Multi-GPU: one process per GPU over RCCL.  `python bench.py --gpus N` as a plain
+command starts its own N ranks (a fresh `python -m torch.distributed.run` child, spawned before this
+process has touched the GPU) and relays rank 0's line; under an external torch.distributed.run
+(RANK set) it is one of the ranks.  Two forms, both with the tile exchange inside the timed region:
+  --scaling weak   (default, the headline form) every rank renders its own target pose of the same
+                   scene: per-GPU work fixed, images sharded across GPUs first;
+  --scaling strong ONE frame per step: its rays are split into contiguous balanced ranges
+                   (`diner_amd.dist.shard_bounds`), every rank renders its range and the rendered
+                   [rays,4] tiles are all-gathered so that every rank holds the whole frame.
 
 Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
   roofline      dominant kernel (fused point/MLP kernel, MFMA-bound): algorithmic FLOP per launch
@@ -21,24 +28,16 @@ Rank 0 prints ONE JSON line (contract in the task description) with two extra ob
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 from pathlib import Path
 
-# the hosts of this pool only support dmabuf IPC (RCCL / cross-process device memory): must be set before HIP starts
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 ROOT = Path(__file__).resolve().parent
-sys.path.insert(0, str(ROOT))
-
-from diner_amd import NeRFRendererDGS, synth  # noqa: E402
-from diner_amd.dist import all_gather_tiles  # noqa: E402
-from diner_amd.model_stub import model_from_scene  # noqa: E402
 
 # dense MFMA peaks, /opt/skills/guides/MI355X_MICROARCH.md (never the 2:1-sparsity marketing figures)
 PEAK_MFMA_TFLOPS = {"fp32": 157.3, "f16x3": 2500.0}
@@ -46,21 +45,82 @@ MFMA_PASSES = {"fp32": 1, "f16x3": 3}   # f16x3: three fp16 MFMAs per fp32 produ
 PEAK_HBM_GBS = 8000.0                   # HBM3E spec peak, same guide
 
 CONFIGS = {
-    # BASELINE.json configs[1]: DTU-like single scene 256x256, 4 views, 128 samples/ray
-    "cfg2": dict(H=256, W=256, NV=4, K=128, G=48, NC=1000, dataset="dtu",
+    # BASELINE.json configs[1]: DTU single scene 256x256, 4 views, 128 samples/ray (DTU near/far, black background)
+    "cfg2": dict(H=256, W=256, NV=4, K=128, G=48, NC=1000, dataset="dtu", poses=8, cpu_rays=2048,
                  desc="cfg2: DTU-like scene, 256x256 target, 4 src views 256x256, K=128 (G=48), NC=1000"),
     # BASELINE.json configs[2] -- the configuration the metric is quoted on (512x512, 4 views, 128 samples)
-    "cfg3": dict(H=512, W=512, NV=4, K=128, G=48, NC=1000, dataset="facescape",
+    "cfg3": dict(H=512, W=512, NV=4, K=128, G=48, NC=1000, dataset="facescape", poses=8, cpu_rays=2048,
                  desc="cfg3: Facescape-like head, 512x512 target, 4 src views 512x512, K=128 (G=48), NC=1000, "
                       "depth-guided sampling on"),
-    # BASELINE.json configs[4] (stress: 8 source views, 256 samples/ray) at a quarter of its image size so that a frame
-    # costs about as much as a cfg3 frame; not the headline, a scaling data point
-    "cfg5s": dict(H=256, W=256, NV=8, K=256, G=96, NC=1000, dataset="facescape",
+    # BASELINE.json configs[3]: DTU val set 512x640 (non-square, configs/train_dtu.yaml:52-58, src/data/dtu.py:42-43),
+    # 16 distinct target poses of the same scene stand in for the val images
+    "cfg4": dict(H=512, W=640, NV=4, K=128, G=48, NC=1000, dataset="dtu", poses=16, cpu_rays=2048,
+                 desc="cfg4: DTU-like scene, 512x640 target, 4 src views 512x640, K=128 (G=48), NC=1000, black background, "
+                      "16 target poses"),
+    # BASELINE.json configs[4] (stress): 1024x1024, 8 source views, 256 samples/ray; latent 576x576x512x8 = 5.4 GB,
+    # lin_z maps 16 GB, 268 M points per frame
+    "cfg5": dict(H=1024, W=1024, NV=8, K=256, G=96, NC=1000, dataset="facescape", poses=8, cpu_rays=384,
+                 desc="cfg5: Facescape-like head, 1024x1024 target, 8 src views 1024x1024, K=256 (G=96), NC=1000"),
+    # the cfg5 parameters at a quarter of its image size (a frame costs about as much as a cfg3 frame)
+    "cfg5s": dict(H=256, W=256, NV=8, K=256, G=96, NC=1000, dataset="facescape", poses=8, cpu_rays=512,
                   desc="cfg5s: Facescape-like head, 256x256 target, 8 src views 256x256, K=256 (G=96), NC=1000"),
+    # cfg4's shape (non-square, DTU, pose cycling) at plumbing size
+    "cfg4s": dict(H=48, W=60, NV=4, K=64, G=24, NC=1000, dataset="dtu", poses=16, cpu_rays=256,
+                  desc="cfg4s: cfg4's shape at 48x60 (plumbing only)"),
     # small plumbing config for quick checks
-    "tiny": dict(H=64, W=64, NV=4, K=64, G=24, NC=1000, dataset="facescape",
+    "tiny": dict(H=64, W=64, NV=4, K=64, G=24, NC=1000, dataset="facescape", poses=8, cpu_rays=256,
                  desc="tiny: 64x64 target, 4 src views, K=64 (plumbing only)"),
 }
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = one frame per GPU per step (default); strong = one frame per step split over the GPUs")
+    ap.add_argument("--rays-per-call", type=int, default=0, help="0 = whole frame in one launch (native mode); "
+                    "4096 = the reference's ray_batch_size (src/models/diner.py:57)")
+    ap.add_argument("--cpu-sample-rays", type=int, default=0, help="rays of the cpu_baseline sample (0 = the config's default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the cpu_baseline / exact-fp32 / 4096-ray legs")
+    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32"], help="arithmetic of the fusion-MLP GEMMs")
+    # CPU rehearsal of the launcher + sharding + gather + one-line contract (tests/test_bench_launch.py): gloo backend,
+    # host tensors and a stub tile producer instead of the HIP render path.  Never a measurement.
+    ap.add_argument("--stub-cpu", action="store_true", help=argparse.SUPPRESS)
+    return ap.parse_args(argv)
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args, argv) -> int:
+    """`python bench.py --gpus N` outside torch.distributed.run: start the N ranks as a fresh child
+    (this process has not imported torch or touched HIP yet), relay rank 0's JSON line, return the child's status."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), str(Path(__file__).resolve())] + list(argv)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for l in p.stdout.splitlines():
+        if l.startswith('{"metric"'):
+            line = l
+        elif l.strip():
+            print(l, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    elif p.returncode == 0:
+        print("bench.py: the ranks exited without a result line", file=sys.stderr)
+        return 1
+    return p.returncode
 
 
 def flops_per_ray(K, NV):
@@ -81,42 +141,76 @@ def host_cores():
     return n
 
 
-def traffic_bytes(args):
-    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/
-    (2*FETCH_SIZE + WRITE_SIZE in KiB -> bytes, the gfx950 correction of the microarch guide); PMC runs
-    are separate rocprofv3 passes, so this is a recorded figure for the default workload, else null."""
+KERNEL_SOURCES = ("points_mlp_f16.hip", "points_mlp.hip", "common.hpp", "Makefile")
+
+
+def kernel_source_digest() -> str:
+    """sha256 (16 hex) over the sources the dominant kernel is built from: ties a recorded PMC figure to a kernel version
+    (.git does not travel to the GPU box, the sources do)."""
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update((ROOT / "diner_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def traffic_record(args):
+    """HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the run (rocprofv3 collects them
+    in separate passes), so this is the figure tools/pmc_summary.py recorded in profiles/traffic.json from such passes of this
+    very command -- used only if the kernel sources still hash to what was profiled, else null.  Bytes = (2*FETCH_SIZE +
+    WRITE_SIZE) KiB, the gfx950 correction of MI355X_MICROARCH.md; they are L2-miss bytes, i.e. Infinity-Cache hits are included."""
     p = ROOT / "profiles" / "traffic.json"
     if not p.exists():
-        return None
-    rec = json.loads(p.read_text())
-    return rec.get(f"{args.config}:{args.precision}:{args.rays_per_call}")
+        return None, "no profiles/traffic.json"
+    rec = json.loads(p.read_text()).get(f"{args.config}:{args.precision}:{args.rays_per_call}")
+    if not isinstance(rec, dict):
+        return None, "no PMC pass recorded for this config"
+    if rec.get("kernel_src_sha16") != kernel_source_digest():
+        return None, f"stale: {rec.get('source')} was taken with kernel sources {rec.get('kernel_src_sha16')}"
+    return rec["bytes_per_launch"], rec.get("source")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
-    ap.add_argument("--rays-per-call", type=int, default=0, help="0 = whole frame in one launch (native mode); "
-                    "4096 = the reference's ray_batch_size (src/models/diner.py:57)")
-    ap.add_argument("--cpu-sample-rays", type=int, default=2048)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f16x3", choices=["f16x3", "fp32"], help="arithmetic of the fusion-MLP GEMMs")
-    args = ap.parse_args()
+def stub_tile(rays):
+    """CPU rehearsal only (--stub-cpu): a deterministic function of the rays standing in for the render."""
+    import torch
+    r = rays[0]
+    return torch.cat([r[:, 3:6] * 0.5 + 0.5, (r[:, 6:7] + r[:, 7:8]) * 0.5], 1).contiguous()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args, argv))
+
+    # the hosts of this pool only support dmabuf IPC (RCCL / cross-process device memory): must be set before HIP starts
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import numpy as np
+    import torch
+    sys.path.insert(0, str(ROOT))
+    from diner_amd import synth
+    from diner_amd.dist import all_gather_tiles, shard_bounds
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    assert world == args.gpus or world == 1 and args.gpus == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    stub = args.stub_cpu
+    if stub:
+        dev = torch.device("cpu")
+    else:
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if stub:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    strong = args.scaling == "strong" and world > 1
 
     cfg = CONFIGS[args.config]
     H, W, NV, K, G, NC = cfg["H"], cfg["W"], cfg["NV"], cfg["K"], cfg["G"], cfg["NC"]
@@ -124,108 +218,163 @@ def main():
     # ---- synthetic scene, resident in HBM before the timed region ------------
     scene = synth.make_scene(H, W, NV, seed=0, dataset=cfg["dataset"], with_latent=False)
     h, w = scene.latent_hw
-    gen = torch.Generator(device=dev).manual_seed(1234)
-    latent = torch.randn((1, NV, 512, h, w), generator=gen, device=dev, dtype=torch.float32)
-    weights = synth.make_mlp_weights(7, bias_scale=0.1)  # seed with sigma > 0 almost everywhere: a meaningful parity sample
-    model = model_from_scene(scene, weights, device=dev, latent=latent)
-    rend = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G, white_bkgd=scene.white_bkgd)
-    rend.precision = args.precision
-    # each rank renders its own target pose of the scene (weak scaling)
-    scene.target_extrinsics = synth.look_at_origin_w2c(0.1 + 0.07 * rank, scene.meta["cam_radius"])
-    rays = torch.from_numpy(scene.target_rays()).to(dev)  # [1, H*W, 8]
-    NR = rays.shape[1]
-    rpc = args.rays_per_call if args.rays_per_call > 0 else NR
-    chunks = list(torch.split(rays, rpc, dim=1))
-    tile = torch.empty((NR, 4), dtype=torch.float32, device=dev)
+    rend = model = latent = weights = None
+    if not stub:
+        from diner_amd import NeRFRendererDGS
+        from diner_amd.model_stub import model_from_scene
+        gen = torch.Generator(device=dev).manual_seed(1234)
+        latent = torch.randn((1, NV, 512, h, w), generator=gen, device=dev, dtype=torch.float32)
+        weights = synth.make_mlp_weights(7, bias_scale=0.1)  # seed with sigma > 0 almost everywhere: a meaningful parity sample
+        model = model_from_scene(scene, weights, device=dev, latent=latent)
+        rend = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G, white_bkgd=scene.white_bkgd)
+        rend.precision = args.precision
+    # target poses: weak = every rank renders its own pose in every step; strong = all ranks share the step's pose
+    n_poses = cfg["poses"]
+    yaws = np.linspace(-0.4, 0.45, n_poses) if args.config.startswith("cfg4") else 0.1 + 0.07 * np.arange(n_poses)
 
-    def step():
+    def rays_of_pose(pi):
+        scene.target_extrinsics = synth.look_at_origin_w2c(float(yaws[pi % n_poses]), scene.meta["cam_radius"])
+        return torch.from_numpy(scene.target_rays()).to(dev)  # [1, H*W, 8]
+
+    NR = H * W
+    lo, hi = shard_bounds(NR, world, rank) if strong else (0, NR)
+    n_mine = hi - lo
+    my_poses = sorted({(i if strong else i * world + rank) % n_poses for i in range(args.steps + args.warmup)})
+    if not args.config.startswith("cfg4"):  # one fixed pose per rank (weak) / one pose (strong), as in round 1
+        my_poses = [0 if strong else rank % n_poses]
+    rays_by_pose = {pi: rays_of_pose(pi)[:, lo:hi].contiguous() for pi in my_poses}
+    rpc = args.rays_per_call if args.rays_per_call > 0 else n_mine
+    tile = torch.empty((n_mine, 4), dtype=torch.float32, device=dev)
+    n_gathered = NR if strong else world * NR
+
+    def render_into_tile(rays):
         o = 0
-        for ch in chunks:
-            out = rend(model, ch)
+        for ch in torch.split(rays, rpc, dim=1):
             n = ch.shape[1]
-            tile[o:o + n, :3] = out.fine.rgb[0]
-            tile[o:o + n, 3] = out.fine.depth[0]
+            if stub:
+                tile[o:o + n] = stub_tile(ch)
+            else:
+                out = rend(model, ch)
+                tile[o:o + n, :3] = out.fine.rgb[0]
+                tile[o:o + n, 3] = out.fine.depth[0]
             o += n
-        return all_gather_tiles(tile, world * NR, world)  # one RCCL all-gather of the [rays,4] tiles per frame
+
+    def step(i):
+        pi = my_poses[0] if len(my_poses) == 1 else (i if strong else i * world + rank) % n_poses
+        render_into_tile(rays_by_pose[pi])
+        return all_gather_tiles(tile, n_gathered, world)  # one RCCL all-gather of the [rays,4] tiles per frame
 
     def fence():
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not stub:
+            torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
-            step()
-        rend.stage_events = []
+        for i in range(args.warmup):
+            frame = step(i)
+        if rend is not None:
+            rend.stage_events = []
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        for i in range(args.steps):
+            frame = step(args.warmup + i)
         fence()
         elapsed = time.perf_counter() - t0
-        events, rend.stage_events = rend.stage_events, None
+        events = []
+        if rend is not None:
+            events, rend.stage_events = rend.stage_events, None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    assert frame.shape[0] == n_gathered
+    stub_ok = None
+    if stub:  # rehearsal: the gathered frame must be what one process would have produced
+        last = args.warmup + args.steps - 1
+        if strong:
+            want = stub_tile(rays_of_pose(my_poses[0] if len(my_poses) == 1 else last % n_poses))
+        else:
+            want = torch.cat([stub_tile(rays_of_pose(r % n_poses if not args.config.startswith("cfg4") else (last * world + r) % n_poses))
+                              for r in range(world)], 0)
+        stub_ok = bool(torch.equal(frame, want))
 
-    # ---- per-kernel durations from the HIP events recorded inside the timed region --------------
-    ms = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in events])  # [launches, 3]
-    t_samp, t_mlp, t_comp = [float(x) for x in ms.mean(0)]
-    rays_per_launch = rpc if len(chunks) > 1 else NR
-    f_launch = flops_per_ray(K, NV) * rays_per_launch          # algorithmic FLOP of the reference's MLP
-    achieved_tflops = f_launch / (t_mlp * 1e-3) / 1e12
-    # what the matrix cores actually execute: with the lin_z maps, 3 of the 9 per-view 512x512 layers are
-    # pre-multiplied once per encode (diner_pack_linz_maps) and leave the per-point kernel
-    linz = args.precision == "f16x3" and rend.linz_maps
-    f_exec = K * 2 * (NV * (2_387_456 - (3 * 512 * 512 if linz else 0)) + 1_050_624) * rays_per_launch * MFMA_PASSES[args.precision]
-    peak = PEAK_MFMA_TFLOPS[args.precision]
-    b_s, b_c = 32 + NC * NV * 20 + 4 * K, K * 20 + 32 + 16  # logical bytes/ray
-    si_gbs = (b_s + b_c) * rays_per_launch / ((t_samp + t_comp) * 1e-3) / 1e9
-
+    rays_per_step = NR if strong else world * NR     # rays all ranks rendered per step
     result = {
         "metric": "rendered rays/sec (512x512, 4 src views, 128 samples/ray)",
-        "value": world * NR * args.steps / elapsed,
+        "value": rays_per_step * args.steps / elapsed,
         "unit": "rays/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if strong else "weak",
         "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "f32 (GEMM operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate)",
-        "data": "synthetic",
-        "config": {"workload": cfg["desc"], "rays_per_gpu_per_step": NR, "rays_per_call": rpc,
+        "data": "synthetic" if not stub else "stub (CPU rehearsal of the launcher, not a measurement)",
+        "config": {"workload": cfg["desc"], "rays_per_gpu_per_step": n_mine, "rays_per_call": rpc,
                    "source_views": NV, "samples_per_ray": K, "n_gaussian": G, "n_candidates": NC,
-                   "parallelism": f"rays sharded x{world} (one target frame per GPU), RCCL all-gather of [rays,4] tiles"
-                   if world > 1 else "single GPU"},
-        "roofline": {"kernel": "points_mlp_kernel" if args.precision == "fp32" else "points_mlp_f16_kernel",
-                     "bound": "mfma", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved_tflops / peak, "traffic": traffic_bytes(args),
-                     "flop_per_launch": f_launch, "avg_ms": t_mlp,
-                     "mfma_dtype": "f32" if args.precision == "fp32" else "f16",
-                     "executed_tflops": f_exec / (t_mlp * 1e-3) / 1e12,
-                     "executed_frac": f_exec / (t_mlp * 1e-3) / 1e12 / peak,
-                     "note": "achieved = algorithmic FLOP of the reference MLP / kernel time; executed = MFMA FLOP actually "
-                             "issued (x3 passes in f16x3 mode, minus the lin_z layers hoisted to per-encode maps)",
-                     "sampling_integration": {"kernels": "sampler_kernel + composite_kernel", "bound": "hbm",
-                                              "achieved": si_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                              "frac": si_gbs / PEAK_HBM_GBS, "logical_bytes_per_ray": b_s + b_c,
-                                              "avg_ms": [t_samp, t_comp]}},
+                   "parallelism": ("single GPU" if world == 1 else
+                                   f"one frame's rays split into {world} contiguous ranges, RCCL all-gather of [rays,4] tiles" if strong else
+                                   f"rays sharded x{world} (one target frame per GPU), RCCL all-gather of [rays,4] tiles")},
     }
 
-    # ---- the same frame with exact fp32 MFMA (v_mfma_f32_32x32x2_f32) for reference, N=1 only: the default
-    #      f16x3 mode is an fp32-grade emulation (parity tests hold both modes to the same bars), this shows what
-    #      the emulation buys and that nothing hides behind it
-    if rank == 0 and world == 1 and args.precision == "f16x3" and not args.no_cpu_baseline:
+    if not stub:
+        # ---- per-kernel durations from the HIP events recorded inside the timed region --------------
+        ms = np.array([[e[i].elapsed_time(e[i + 1]) for i in range(3)] for e in events])  # [launches, 3]
+        t_samp, t_mlp, t_comp = [float(x) for x in ms.mean(0)]
+        rays_per_launch = min(rpc, n_mine)
+        f_launch = flops_per_ray(K, NV) * rays_per_launch          # algorithmic FLOP of the reference's MLP
+        achieved_tflops = f_launch / (t_mlp * 1e-3) / 1e12
+        # what the matrix cores actually execute: with the lin_z maps, 3 of the 9 per-view 512x512 layers are
+        # pre-multiplied once per encode (diner_pack_linz_maps) and leave the per-point kernel; the last per-view fc_1
+        # is applied once to the view mean (it commutes with the mean)
+        linz = args.precision == "f16x3" and rend.linz_maps
+        macs = NV * (2_387_456 - (3 * 512 * 512 if linz else 0)) + 1_050_624
+        if args.precision == "f16x3" and getattr(rend, "fc1_on_mean", False):
+            macs -= (NV - 1) * 512 * 512
+        f_exec = K * 2 * macs * rays_per_launch * MFMA_PASSES[args.precision]
+        peak = PEAK_MFMA_TFLOPS[args.precision]
+        b_s, b_c = 32 + NC * NV * 20 + 4 * K, K * 20 + 32 + 16  # logical bytes/ray
+        si_gbs = (b_s + b_c) * rays_per_launch / ((t_samp + t_comp) * 1e-3) / 1e9
+        traffic, traffic_source = traffic_record(args)
+        result["roofline"] = {
+            "kernel": "points_mlp_kernel" if args.precision == "fp32" else "points_mlp_f16_kernel",
+            "bound": "mfma", "achieved": achieved_tflops, "peak": peak, "unit": "TFLOP/s",
+            "frac": achieved_tflops / peak, "traffic": traffic, "traffic_source": traffic_source,
+            "flop_per_launch": f_launch, "avg_ms": t_mlp,
+            "mfma_dtype": "f32" if args.precision == "fp32" else "f16",
+            "executed_tflops": f_exec / (t_mlp * 1e-3) / 1e12,
+            "executed_frac": f_exec / (t_mlp * 1e-3) / 1e12 / peak,
+            "note": "achieved = algorithmic FLOP of the reference MLP / kernel time; executed = MFMA FLOP actually "
+                    "issued (x3 passes in f16x3 mode, minus the layers hoisted out of the per-point path); traffic = L2-miss "
+                    "bytes (HBM + Infinity Cache) of a recorded PMC pass of this command, null when the kernel changed since",
+            "sampling_integration": {"kernels": "sampler_kernel + composite_kernel", "bound": "latency/VALU (maps are cache-served); "
+                                     "fraction quoted on SURVEY §8(d)'s logical bytes",
+                                     "achieved": si_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                     "frac": si_gbs / PEAK_HBM_GBS, "logical_bytes_per_ray": b_s + b_c,
+                                     "avg_ms": [t_samp, t_comp]}}
+    else:
+        result["roofline"] = None
+        result["stub_frame_ok"] = stub_ok
+
+    extras = rank == 0 and world == 1 and not args.no_cpu_baseline and not stub
+    if extras:
+        rays = rays_by_pose[my_poses[0]]
+
+    # ---- the same frame with exact fp32 MFMA (v_mfma_f32_32x32x2_f32) for reference, N=1 cfg3/cfg2/tiny only: the
+    #      default f16x3 mode is an fp32-grade emulation (parity tests hold both modes to the same bars), this shows
+    #      what the emulation buys and that nothing hides behind it
+    if extras and args.precision == "f16x3" and NR * K * NV <= 512 * 512 * 128 * 4:
         rend.precision = "fp32"
         with torch.no_grad():
-            step()
+            render_into_tile(rays)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            step()
+            render_into_tile(rays)
             torch.cuda.synchronize()
             t_fp32 = time.perf_counter() - t0
         rend.precision = args.precision
@@ -234,7 +383,7 @@ def main():
 
     # ---- the same frame in the reference's call granularity (ray_batch_size 4096, src/models/diner.py:57): SURVEY.md
     #      §8(d) asks for both the whole-frame launch (`value`) and this one
-    if rank == 0 and world == 1 and len(chunks) == 1 and NR > 4096 and not args.no_cpu_baseline:
+    if extras and rpc == NR and 4096 < NR <= 512 * 640:
         small = list(torch.split(rays, 4096, dim=1))
         with torch.no_grad():
             for ch in small[:4]:
@@ -253,10 +402,10 @@ def main():
         result["rays_per_call_4096"] = {"value": NR / t_small, "unit": "rays/s", "ms_per_frame": t_small * 1e3, "calls": len(small)}
 
     # ---- CPU baseline: the oracle (C port of the reference algorithm) on a bounded sample ---------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if extras:
         from oracle.oracle import Oracle
         cores = host_cores()
-        n_s = min(args.cpu_sample_rays, NR)
+        n_s = min(args.cpu_sample_rays or cfg["cpu_rays"], NR)
         sel = np.linspace(0, NR - 1, n_s).astype(np.int64)
         rays_s = np.ascontiguousarray(rays.cpu().numpy()[:, sel])
         scene.latent = latent.cpu().numpy()
@@ -274,7 +423,7 @@ def main():
         result["parity_on_sample"] = {"rays": int(n_s), "frac_rays_rgb_within_1e-4": float((d <= 1e-4).mean()),
                                       "max_abs_rgb_diff": float(d.max()), "median_abs_rgb_diff": float(np.median(d))}
     if rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

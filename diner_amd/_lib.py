@@ -60,7 +60,7 @@ SYMBOLS = {
     "diner_fill_up_uniform_samples": (C.c_int, [_P, _P, _I64, _I32, _P, _U64, _P, _P]),
     "diner_render_points_scratch_floats": (_I64, [_I64, _I32, _I32]),
     "diner_render_points": (C.c_int, [C.POINTER(DinerScene), _P, _P, _P, _I64, _I32, _I32, _P, _P, _P]),
-    "diner_composite": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),
+    "diner_composite": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P, _P]),
     "diner_decode_depth_u16": (C.c_int, [_P, _P, _P, _I64, _I32, _I32, _I32, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float,
                                          _P, _P, _P, _P]),
     "diner_train_gemm": (C.c_int, [_P, _P, _P, _P, _P, _I64, _I32, _I32, _I64, _I64, _I64, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _I64,
@@ -78,7 +78,7 @@ SYMBOLS = {
     "diner_composite_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "diner_render_workspace_floats": (_I64, [_I64, _I64, _I32, _I32, _I32]),
     "diner_render": (C.c_int, [C.POINTER(DinerScene), _P, _P, _I64, C.POINTER(DinerSamplerCfg), _I32, _I32,
-                               _P, _P, _P, _U64, _P, _P, _P, _P, _P]),
+                               _P, _P, _P, _U64, _P, _P, _P, _P, _P, _P]),
 }
 
 _lib = None

@@ -27,7 +27,7 @@ int check_launch(const char *what)
     return DINER_OK;
 }
 
-int launch_composite(const float *, const float *, const float *, int64_t, int, int, float *, float *, float *, hipStream_t);
+int launch_composite(const float *, const float *, const float *, int64_t, int, int, float *, float *, float *, unsigned int *, hipStream_t);
 int launch_pack_maps(const float *, const float *, const float *, int64_t, int, int, float *, hipStream_t);
 int launch_pack_latent(const float *, int64_t, int, int, int, float *, hipStream_t);
 int launch_pack_mlp(const DinerMlpRaw &, float *, hipStream_t);
@@ -100,7 +100,7 @@ using namespace diner;
 extern "C" {
 
 const char *diner_last_error(void) { return g_err; }
-int diner_version(void) { return 1; }
+int diner_version(void) { return 2; }
 
 int diner_gen_rays(const float *extrinsics, const float *intrinsics, const float *z_near, const float *z_far, int32_t B,
                    int32_t H, int32_t W, float *rays_out, void *stream)
@@ -223,11 +223,11 @@ int diner_render_points(const DinerScene *scene, const float *mlp_packed, const 
 }
 
 int diner_composite(const float *rays, const float *z, const float *rgbsigma, int64_t N, int32_t K,
-                    int32_t white_bkgd, float *rgb_out, float *depth_out, float *weights_out, void *stream)
+                    int32_t white_bkgd, float *rgb_out, float *depth_out, float *weights_out, uint32_t *status, void *stream)
 {
     if (N < 0 || K < 1) return bad("composite: bad N / K");
     if (N > 0 && (!rays || !z || !rgbsigma || !rgb_out || !depth_out)) return bad("composite: NULL pointer");
-    return launch_composite(rays, z, rgbsigma, N, K, white_bkgd, rgb_out, depth_out, weights_out, (hipStream_t)stream);
+    return launch_composite(rays, z, rgbsigma, N, K, white_bkgd, rgb_out, depth_out, weights_out, status, (hipStream_t)stream);
 }
 
 /* ---- training path building blocks (train.hip) ------------------------------------------------ */
@@ -334,7 +334,7 @@ int64_t diner_render_workspace_floats(int64_t SB, int64_t NR, int32_t K, int32_t
 int diner_render(const DinerScene *scene, const float *mlp_packed, const float *rays, int64_t NR,
                  const DinerSamplerCfg *cfg, int32_t white_bkgd, int32_t precision, const float *u_coarse, const float *n_gauss,
                  const float *u_fill, uint64_t seed, float *workspace, float *rgb_out, float *depth_out,
-                 float *weights_out, void *stream)
+                 float *weights_out, uint32_t *status, void *stream)
 {
     int rc;
     if ((rc = check_scene(scene, true)) || (rc = check_cfg(cfg))) return rc;
@@ -347,7 +347,7 @@ int diner_render(const DinerScene *scene, const float *mlp_packed, const float *
                                        nullptr, stream)))
         return rc;
     if ((rc = diner_render_points(scene, mlp_packed, rays, z, NR, cfg->n_samples, precision, scratch, rgbsigma, stream))) return rc;
-    return diner_composite(rays, z, rgbsigma, N, cfg->n_samples, white_bkgd, rgb_out, depth_out, weights_out, stream);
+    return diner_composite(rays, z, rgbsigma, N, cfg->n_samples, white_bkgd, rgb_out, depth_out, weights_out, status, stream);
 }
 
 }  // extern "C"

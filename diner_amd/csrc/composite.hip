@@ -15,7 +15,7 @@ constexpr int COMPOSITE_WAVES = 4;  // rays per 256-thread workgroup
 __global__ __launch_bounds__(COMPOSITE_WAVES * 64) void composite_kernel(
     const float *__restrict__ rays, const float *__restrict__ z, const float4 *__restrict__ rgbsigma,
     int64_t N, int K, int white_bkgd, float *__restrict__ rgb_out, float *__restrict__ depth_out,
-    float *__restrict__ weights_out)
+    float *__restrict__ weights_out, unsigned int *__restrict__ status)
 {
     const int lane = threadIdx.x & 63;
     const int64_t ray = (int64_t)blockIdx.x * COMPOSITE_WAVES + (threadIdx.x >> 6);
@@ -24,6 +24,7 @@ __global__ __launch_bounds__(COMPOSITE_WAVES * 64) void composite_kernel(
     const float *zr = z + ray * K;
     const float4 *cr = rgbsigma + ray * K;
     float carry = 1.0f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_w = 0.f;
+    bool bad = false;  // a non-finite rgb-sigma sample (an MLP activation left the range of the arithmetic in use)
     for (int k0 = 0; k0 < K; k0 += 64) {
         const int k = k0 + lane;
         const bool on = k < K;
@@ -35,7 +36,8 @@ __global__ __launch_bounds__(COMPOSITE_WAVES * 64) void composite_kernel(
             c = cr[k];
         }
         const float delta = zn - zk;
-        const float sg = c.w > 0.0f ? c.w : 0.0f;      // relu applied again (:344)
+        bad |= !(__builtin_isfinite(c.x) && __builtin_isfinite(c.y) && __builtin_isfinite(c.z) && __builtin_isfinite(c.w));
+        const float sg = c.w < 0.0f ? 0.0f : c.w;      // relu applied again (:344); NaN stays NaN like torch.relu
         float alpha = 1.0f - expf(-delta * sg);
         float keep = 1.0f - alpha + 1e-10f;            // :347-349
         if (!on) { alpha = 0.0f; keep = 1.0f; }
@@ -52,6 +54,7 @@ __global__ __launch_bounds__(COMPOSITE_WAVES * 64) void composite_kernel(
     }
     acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b);
     acc_d = wave_sum(acc_d); acc_w = wave_sum(acc_w);
+    if (status && __any(bad) && lane == 0) atomicOr(status, DINER_STATUS_NONFINITE);  // rare: only when something is wrong
     if (lane == 0) {
         if (white_bkgd) {                               // :357-360
             acc_r = acc_r + 1.0f - acc_w; acc_g = acc_g + 1.0f - acc_w; acc_b = acc_b + 1.0f - acc_w;
@@ -62,12 +65,12 @@ __global__ __launch_bounds__(COMPOSITE_WAVES * 64) void composite_kernel(
 }
 
 int launch_composite(const float *rays, const float *z, const float *rgbsigma, int64_t N, int K,
-                     int white_bkgd, float *rgb, float *depth, float *weights, hipStream_t st)
+                     int white_bkgd, float *rgb, float *depth, float *weights, unsigned int *status, hipStream_t st)
 {
     if (N == 0) return DINER_OK;
     const int64_t blocks = (N + COMPOSITE_WAVES - 1) / COMPOSITE_WAVES;
     hipLaunchKernelGGL(composite_kernel, dim3((unsigned)blocks), dim3(COMPOSITE_WAVES * 64), 0, st, rays, z,
-                       (const float4 *)rgbsigma, N, K, white_bkgd, rgb, depth, weights);
+                       (const float4 *)rgbsigma, N, K, white_bkgd, rgb, depth, weights, status);
     return check_launch("composite_kernel");
 }
 

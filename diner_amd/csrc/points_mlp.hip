@@ -159,7 +159,7 @@ __device__ __forceinline__ void store_relu(const f32x16 (&acc)[2][CT], float *A,
             for (int i = 0; i < 16; ++i) {
                 const int row = tm * 32 + 8 * (i >> 2) + 4 * h + (i & 3);  // C/D layout of the 32x32 MFMA
                 const float v = acc[tm][tn][i];
-                col[row << 2] = v > 0.0f ? v : 0.0f;
+                col[row << 2] = v < 0.0f ? 0.0f : v;  // keeps NaN, like torch.relu
             }
     }
 }
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_kernel(DinerScene s, c
                 const int64_t pp = tile * TILE_P + r;
                 if (pp < P) {
                     const float val = o[i];                                            // pixelnerf.py:139-143
-                    rgbsigma[((int64_t)sb * P + pp) * 4 + c] = c < 3 ? 1.0f / (1.0f + expf(-val)) : (val > 0.0f ? val : 0.0f);
+                    rgbsigma[((int64_t)sb * P + pp) * 4 + c] = c < 3 ? 1.0f / (1.0f + expf(-val)) : (val < 0.0f ? 0.0f : val);
                 }
             }
         }

@@ -12,7 +12,8 @@
 // the representation error of an operand is max(2^-23 |v|, 2^-25): fp32-grade.  The whole hidden
 // state is carried scaled by 2^-4 (inputs and biases are pre-scaled, the head multiplies by 16: all
 // exact), which moves the fp16 overflow point of an activation to 1.0e6 at no cost in the hot loops.
-// An activation beyond the fp16 range becomes inf and the outputs NaN -- loud, never silently wrong.
+// An activation beyond the fp16 range becomes inf, the next product NaN, and every ReLU here keeps NaN (v < 0 ? 0 : v,
+// like torch.relu), so the sample's rgb-sigma is NaN and the compositing kernel raises DINER_STATUS_NONFINITE.
 // Parity with the reference stays inside the 1e-4 bar (tests/test_gpu_parity.py, both precisions).
 //
 // Why: fp32-input MFMA runs at the vector rate (157 TFLOP/s); fp16 MFMA at ~16x that per
@@ -220,7 +221,7 @@ __device__ __forceinline__ void store_relu(const f32x16 (&acc)[CT][2], _Float16 
                 for (int j = 0; j < 4; ++j) {
                     const float v = acc[tn][tp][4 * g + j];
                     _Float16 hi, lo;
-                    split(v > 0.0f ? v : 0.0f, hi, lo);
+                    split(v < 0.0f ? 0.0f : v, hi, lo);  // relu that keeps NaN (torch.relu does): a blown-up activation stays visible
                     vh[j] = hi;
                     vl[j] = lo;
                 }
@@ -537,7 +538,7 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_f16_kernel(DinerScene 
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const float val = (o[j] + bias[14 * 512 + j]) * (1.0f / ACT_SCALE);       // pixelnerf.py:139-143
-                    out[j] = j < 3 ? 1.0f / (1.0f + expf(-val)) : (val > 0.0f ? val : 0.0f);
+                    out[j] = j < 3 ? 1.0f / (1.0f + expf(-val)) : (val < 0.0f ? 0.0f : val);
                 }
                 *(f32x4 *)(rgbsigma + ((int64_t)sb * P + pp) * 4) = out;
             }

@@ -78,7 +78,7 @@ __device__ __forceinline__ void tile_store(float (*T)[LDT], const f32x4 (&v)[2],
         const int idx = tid + 256 * i;
         f32x4 x = v[i];
         const float lo = relu ? 0.f : -__builtin_inff();
-        for (int j = 0; j < 4; ++j) x[j] = ((ok >> i) & 1u) ? fmaxf(x[j], lo) : 0.f;
+        for (int j = 0; j < 4; ++j) x[j] = ((ok >> i) & 1u) ? (x[j] < lo ? lo : x[j]) : 0.f;  // NaN-keeping floor (fmaxf would launder NaN into 0)
         if (KC) {
             const int l = idx >> 2, kq = (idx & 3) * 4;
 #pragma unroll
@@ -259,7 +259,7 @@ __device__ __forceinline__ void put4(h8 *Thi, h8 *Tlo, int l, int kq, float x0, 
     h4 hi, lo;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float t = fmaxf(x[j] * sc, floor_);  // floor_ = 0 applies the relu, -inf does nothing
+        const float ts = x[j] * sc, t = ts < floor_ ? floor_ : ts;  // floor_ = 0 applies the relu, -inf does nothing; NaN stays NaN
         hi[j] = (_Float16)t;
         lo[j] = (_Float16)(t - (float)hi[j]);
     }
@@ -480,7 +480,7 @@ __device__ __forceinline__ void store_a(h8 *T, const StageA &st, float floor_, f
         h4 hi, lo;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float t = ((st.ok >> i) & 1u) ? fmaxf(st.a[i][j] * sc, floor_) : 0.0f;
+            const float ts = st.a[i][j] * sc, t = ((st.ok >> i) & 1u) ? (ts < floor_ ? floor_ : ts) : 0.0f;
             hi[j] = (_Float16)t;
             lo[j] = (_Float16)(t - (float)hi[j]);
         }
@@ -829,7 +829,7 @@ __global__ void head_kernel(const float *__restrict__ out, int64_t n4, float *__
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
     const float v = out[i];
-    rgbsigma[i] = (i & 3) < 3 ? 1.0f / (1.0f + expf(-v)) : (v > 0.0f ? v : 0.0f);
+    rgbsigma[i] = (i & 3) < 3 ? 1.0f / (1.0f + expf(-v)) : (v < 0.0f ? 0.0f : v);
 }
 __global__ void head_bwd_kernel(const float *__restrict__ out, const float *__restrict__ rgbsigma, const float *__restrict__ d_rgbsigma,
                                 int64_t n4, float *__restrict__ d_out)

@@ -12,12 +12,17 @@ All arithmetic runs in the hand-written HIP kernels of ``libdiner_hip.so`` throu
 eager fallback: without the library the import of this module's dependencies fails.
 
 The module holds no parameters or buffers (reference checkpoints load with ``strict=True``); it
-keeps an identity-keyed cache of re-packed copies of the model's maps and MLP weights
-(invalidated when a tensor's ``data_ptr``/``_version``/shape changes).
+keeps an identity-keyed cache of re-packed copies of the model's maps and MLP weights: an entry is
+valid only while the very tensor OBJECTS it was packed from are alive (weak references, compared with
+``is``) and their ``_version`` counters are unchanged -- a fresh tensor that the caching allocator
+happens to place at a freed tensor's address is a different object and invalidates the entry, as does
+every ``encode()`` of the reference, which re-binds ``encoder.latent/depths/...`` to new tensors
+(src/models/image_encoder.py:214-218,271-272).  No strong reference to the sources is kept.
 """
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -39,8 +44,21 @@ class RenderOutput(dict):
         self[k] = v
 
 
-def _sig(t: torch.Tensor):
-    return (t.data_ptr(), t._version, tuple(t.shape), t.dtype, str(t.device))
+class _Sources:
+    """Identity + version of the tensors a packed copy was made from (SURVEY.md §8(b) ownership row): weak
+    references only, so the cache neither extends a source's lifetime nor can be fooled by address reuse."""
+
+    __slots__ = ("refs", "versions", "shapes")
+
+    def __init__(self, tensors):
+        self.refs = [weakref.ref(t) for t in tensors]
+        self.versions = [t._version for t in tensors]
+        self.shapes = [(tuple(t.shape), t.dtype, t.device) for t in tensors]
+
+    def valid_for(self, tensors) -> bool:
+        return len(tensors) == len(self.refs) and all(
+            r() is t and v == t._version and sh == (tuple(t.shape), t.dtype, t.device)
+            for r, v, sh, t in zip(self.refs, self.versions, self.shapes, tensors))
 
 
 def _f32c(t: torch.Tensor) -> torch.Tensor:
@@ -91,6 +109,15 @@ class NeRFRendererDGS(torch.nn.Module):
         self.linz_maps = True
         self._mlp_key = None
         self._mlp_pack = None
+        self._latent_gen = self._mlp_gen = 0         # bumped by every re-pack; the lin_z maps depend on both
+        # Non-finite guard.  The compositing kernel ORs DINER_STATUS_NONFINITE into a device word when an rgb-sigma
+        # sample is inf/NaN (in f16x3 mode: an MLP activation beyond the fp16 range, |x| >= ~1e6).  The word is copied
+        # to pinned host memory behind every call and examined WITHOUT a host sync: "deferred" (default) raises at the
+        # first later call (or check_finite()) that finds the copy complete; "sync" waits at the end of each call
+        # (render_image always does: once per frame); "off" never looks.
+        self.finite_check = "deferred"
+        self._status = None
+        self._pending = []                           # [(event, pinned host word)] oldest first
 
     # ------------------------------------------------------------------------------------------
     # model -> packed device state (cached)
@@ -114,9 +141,8 @@ class NeRFRendererDGS(torch.nn.Module):
     def _scene(self, model, need_latent=True, packed_mlp=None) -> Tuple[DinerScene, tuple]:
         enc = model.encoder
         dev = enc.depths.device
-        mkey = tuple(_sig(t) for t in (model.poses, model.focal, model.c, model.image_shape, enc.depths,
-                                       enc.depths_std, enc.normals))
-        if mkey != self._maps_key:
+        msrc = [model.poses, model.focal, model.c, model.image_shape, enc.depths, enc.depths_std, enc.normals]
+        if self._maps_key is None or not self._maps_key.valid_for(msrc):
             SB, NV, _, H, W = enc.depths.shape
             maps = torch.empty((SB, NV, H, W, 8), dtype=torch.float32, device=dev)
             d, s, n = _f32c(enc.depths), _f32c(enc.depths_std), _f32c(enc.normals)
@@ -130,22 +156,22 @@ class NeRFRendererDGS(torch.nn.Module):
                 poses = full.contiguous()
             torch.cuda.current_stream(dev).synchronize()  # d/s/n may be temporaries
             ishape = [float(v) for v in model.image_shape.detach().float().cpu()]  # (W, H), pixelnerf.py:50-51
-            self._maps_pack, self._maps_key = (maps, poses, _f32c(model.focal), _f32c(model.c), ishape), mkey
+            self._maps_pack, self._maps_key = (maps, poses, _f32c(model.focal), _f32c(model.c), ishape), _Sources(msrc)
         if need_latent:
-            lkey = _sig(enc.latent)
-            if lkey != self._latent_key:
+            if self._latent_key is None or not self._latent_key.valid_for([enc.latent]):
                 lat = _f32c(enc.latent)
                 SB, NV, Cc, h, w = lat.shape
                 latent = torch.empty((SB, NV, h, w, Cc), dtype=torch.float32, device=dev)
                 check(_lib.lib().diner_pack_latent(_ptr(lat), SB * NV, Cc, h, w, _ptr(latent), _stream(dev)),
                       "diner_pack_latent")
                 torch.cuda.current_stream(dev).synchronize()
-                self._latent_pack, self._latent_key = latent, lkey
+                self._latent_pack, self._latent_key = latent, _Sources([enc.latent])
+                self._latent_gen += 1
         maps, poses, focal, c, ishape = self._maps_pack
         latent = self._latent_pack if need_latent else None
         linz = None
         if need_latent and packed_mlp is not None and self.linz_maps and self.precision == "f16x3":
-            zkey = (self._latent_key, self._mlp_key)
+            zkey = (self._latent_gen, self._mlp_gen)   # generations of the two packs the maps were computed from
             if zkey != self._linz_key:
                 SB, NV, h, w, Cc = latent.shape
                 out = torch.empty((3, SB, NV, h, w, Cc), dtype=torch.float32, device=dev)
@@ -176,8 +202,7 @@ class NeRFRendererDGS(torch.nn.Module):
             params += [mlp.lin_z[b].weight, mlp.lin_z[b].bias]
         for b in range(5):
             params += [mlp.blocks[b].fc_0.weight, mlp.blocks[b].fc_0.bias, mlp.blocks[b].fc_1.weight, mlp.blocks[b].fc_1.bias]
-        key = tuple(_sig(p) for p in params)
-        if key != self._mlp_key:
+        if self._mlp_key is None or not self._mlp_key.valid_for(params):
             keep = [_f32c(p) for p in params]
             raw = DinerMlpRaw()
             raw.lin_in_w, raw.lin_in_b, raw.lin_out_w, raw.lin_out_b = [t.data_ptr() for t in keep[:4]]
@@ -191,8 +216,54 @@ class NeRFRendererDGS(torch.nn.Module):
             packed = torch.empty(int(_lib.lib().diner_mlp_packed_floats()), dtype=torch.float32, device=dev)
             check(_lib.lib().diner_pack_mlp(C.byref(raw), _ptr(packed), _stream(dev)), "diner_pack_mlp")
             torch.cuda.current_stream(dev).synchronize()  # `keep` may be temporaries: finish before they die
-            self._mlp_pack, self._mlp_key = packed, key
+            self._mlp_pack, self._mlp_key = packed, _Sources(params)
+            self._mlp_gen += 1
         return self._mlp_pack
+
+    # ------------------------------------------------------------------------------------------
+    # non-finite guard
+    # ------------------------------------------------------------------------------------------
+    def _status_word(self, dev) -> Optional[torch.Tensor]:
+        if self.finite_check == "off":
+            return None
+        if self._status is None or self._status.device != dev:
+            self._status = torch.zeros(1, dtype=torch.int32, device=dev)
+            self._pending = []
+        return self._status
+
+    def _poll_status(self, wait=False):
+        """Examine the completed status copies (all of them if ``wait``); raise if a frame went non-finite."""
+        bad = False
+        while self._pending and (wait or self._pending[0][0].query()):
+            ev, host = self._pending.pop(0)
+            if wait:
+                ev.synchronize()
+            bad |= bool(int(host[0]) & 1)
+        if bad:
+            self._pending = []
+            self._status.zero_()
+            raise RuntimeError(
+                "diner_amd.NeRFRendererDGS: a rendered rgb-sigma sample was inf/NaN" +
+                (" -- in precision='f16x3' an MLP activation left the fp16 range (|x| >= ~1e6, see DESIGN.md); set "
+                 "renderer.precision = 'fp32' (exact fp32 MFMA) for this model" if self.precision == "f16x3" else
+                 " -- the model itself produces non-finite values for these inputs"))
+
+    def _after_launch(self, dev, sync=False):
+        if self._status is None or self.finite_check == "off":
+            return
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(self._status, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self._pending.append((ev, host))
+        if len(self._pending) > 256:                 # never let the list grow without bound
+            self._poll_status(wait=True)
+        elif sync or self.finite_check == "sync":
+            self._poll_status(wait=True)
+
+    def check_finite(self):
+        """Wait for every render issued so far and raise ``RuntimeError`` if one produced inf/NaN samples."""
+        self._poll_status(wait=True)
 
     @staticmethod
     def _check_rays(rays):
@@ -309,8 +380,10 @@ class NeRFRendererDGS(torch.nn.Module):
         weights = torch.empty((SB, NR, K), dtype=torch.float32, device=dev)
         rgb = torch.empty((SB, NR, 3), dtype=torch.float32, device=dev)
         depth = torch.empty((SB, NR), dtype=torch.float32, device=dev)
+        self._poll_status()
         check(_lib.lib().diner_composite(_ptr(r), _ptr(z), _ptr(c), SB * NR, K, int(bool(self.white_bkgd)), _ptr(rgb),
-                                         _ptr(depth), _ptr(weights), _stream(dev)), "diner_composite")
+                                         _ptr(depth), _ptr(weights), _ptr(self._status_word(dev)), _stream(dev)), "diner_composite")
+        self._after_launch(dev)
         return weights, rgb, depth
 
     @staticmethod
@@ -356,10 +429,12 @@ class NeRFRendererDGS(torch.nn.Module):
                 prec = _lib.PRECISIONS[self.precision]
                 ws = torch.empty(int(_lib.lib().diner_render_workspace_floats(SB, NR, K, sc.NV, prec)), dtype=torch.float32, device=dev)
                 L, st, seed = _lib.lib(), _stream(dev), self._next_seed()
+                self._poll_status()
+                status = _ptr(self._status_word(dev))
                 if self.stage_events is None:
                     check(L.diner_render(C.byref(sc), _ptr(packed), _ptr(r), NR, C.byref(cfg), int(bool(self.white_bkgd)),
                                          prec, _ptr(u_c), _ptr(n_g), _ptr(u_f), seed, _ptr(ws), _ptr(rgb), _ptr(depth),
-                                         _ptr(weights), st), "diner_render")
+                                         _ptr(weights), status, st), "diner_render")
                 else:
                     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
                     z, c, scr = ws[:SB * NR * K], ws[SB * NR * K:SB * NR * K * 5], ws[SB * NR * K * 5:]
@@ -372,9 +447,10 @@ class NeRFRendererDGS(torch.nn.Module):
                           "diner_render_points")
                     ev[2].record()
                     check(L.diner_composite(_ptr(r), _ptr(z), _ptr(c), SB * NR, K, int(bool(self.white_bkgd)), _ptr(rgb),
-                                            _ptr(depth), _ptr(weights), st), "diner_composite")
+                                            _ptr(depth), _ptr(weights), status, st), "diner_composite")
                     ev[3].record()
                     self.stage_events.append(ev)
+                self._after_launch(dev)
         return RenderOutput(fine=self._format_outputs(weights, rgb, depth, want_weights=want_weights))
 
     @torch.no_grad()
@@ -392,6 +468,8 @@ class NeRFRendererDGS(torch.nn.Module):
         zf = torch.as_tensor(z_far, dtype=torch.float32, device=dev).expand(SB)
         rays = glue.gen_rays(target_extrinsics, target_intrinsics, W, H, zn, zf).view(SB, H * W, 8)
         out = self.forward(model, rays).fine
+        if self.finite_check != "off":
+            self.check_finite()                      # once per frame: a NaN image never leaves this function
         rgb = out.rgb.view(SB, H, W, 3).permute(0, 3, 1, 2)
         if return_depth:
             return rgb, out.depth.view(SB, H, W, 1).permute(0, 3, 1, 2)

@@ -181,7 +181,7 @@ class _RenderFn(torch.autograd.Function):
             saved.append((in56, zl, taps, xs, nets, xbars, pnets, xbar, out))
         N = SB * NR
         rgb, depth, weights = f(SB, NR, 3), f(SB, NR), f(SB, NR, K)
-        check(L.diner_composite(_p(rays), _p(z), _p(rgbsigma), N, K, int(bool(renderer.white_bkgd)), _p(rgb), _p(depth), _p(weights), st),
+        check(L.diner_composite(_p(rays), _p(z), _p(rgbsigma), N, K, int(bool(renderer.white_bkgd)), _p(rgb), _p(depth), _p(weights), None, st),
               "diner_composite")
         ctx.renderer, ctx.scene, ctx.rays, ctx.z, ctx.rgbsigma = renderer, scene, rays, z, rgbsigma
         ctx.saved_acts, ctx.prm, ctx.w_in56, ctx.lat_shape = saved, prm, w_in56, tuple(latent.shape)

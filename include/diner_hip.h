@@ -168,10 +168,14 @@ int diner_render_points(const DinerScene *scene, const float *mlp_packed, const 
                         float *rgbsigma_out, void *stream);
 
 /* Replaces the alpha compositing of composite() (src/models/nerf_renderer.py:299-301,341-360).
- * N rays (= SB*NR).  weights_out [N,K] optional. */
+ * N rays (= SB*NR).  weights_out [N,K] optional.
+ * status (optional): one device word, OR-ed with DINER_STATUS_NONFINITE when any rgb-sigma sample is inf/NaN
+ * (the reference would hand NaN images on silently; in f16x3 mode it means an activation left the fp16 range,
+ * |x| >= ~1e6, and the frame must be re-rendered with DINER_PRECISION_FP32).  Sticky: the caller clears it. */
+#define DINER_STATUS_NONFINITE 1u
 int diner_composite(const float *rays, const float *z, const float *rgbsigma, int64_t N, int32_t K,
                     int32_t white_bkgd, float *rgb_out, float *depth_out, float *weights_out,
-                    void *stream);
+                    uint32_t *status, void *stream);
 
 /* Replaces NeRFRendererDGS.forward (src/models/nerf_renderer.py:399-424): the three stages
  * back to back on `stream`.  workspace: device buffer of diner_render_workspace_floats(...)
@@ -180,7 +184,7 @@ int64_t diner_render_workspace_floats(int64_t SB, int64_t NR, int32_t K, int32_t
 int diner_render(const DinerScene *scene, const float *mlp_packed, const float *rays, int64_t NR,
                  const DinerSamplerCfg *cfg, int32_t white_bkgd, int32_t precision, const float *u_coarse,
                  const float *n_gauss, const float *u_fill, uint64_t seed, float *workspace,
-                 float *rgb_out, float *depth_out, float *weights_out, void *stream);
+                 float *rgb_out, float *depth_out, float *weights_out, uint32_t *status, void *stream);
 
 /* ---- training path: building blocks of the forward-with-saved-activations and
  * the backward of composite (src/models/nerf_renderer.py:286-365) + PixelNeRF.forward

@@ -41,6 +41,11 @@ CASES = {
     # BASELINE.json's stress configuration: 8 source views, 256 samples per ray (G = 96)
     "g5_nv8_k256_stress": dict(scene=dict(H=48, W=48, NV=8, seed=15, dataset="facescape", feature_padding=32),
                                K=256, NC=1000, G=96, ray_stride=53, focal_scale=1.0, wseed=16, bias_scale=0.1, nseed=17),
+    # BASELINE.json configs[1]/[3] (cfg2 / cfg4): the DTU workload at the headline renderer parameters -- DTU near/far
+    # (src/data/dtu.py:42-43), black background (configs/train_dtu.yaml:58), 4 views, K=128, G=48, NC=1000, NON-SQUARE maps
+    # (64 x 80, the 512 x 640 aspect), dataset-faithful background sigma conf2std(0)
+    "g6_nv4_k128_dtu_nonsquare": dict(scene=dict(H=64, W=80, NV=4, seed=18, dataset="dtu", feature_padding=32),
+                                      K=128, NC=1000, G=48, ray_stride=71, focal_scale=1.0, wseed=19, bias_scale=0.1, nseed=20),
 }
 N_FULL_INPUT_POINTS = 16   # points whose full 567-vector is stored
 N_TAIL_INPUT_POINTS = 512  # points whose 55 non-latent inputs are stored

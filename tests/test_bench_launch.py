@@ -1,0 +1,53 @@
+"""`python bench.py --gpus N` as a plain command (how the driver runs it): bench.py must start its own ranks, shard,
+gather and print ONE contract line.  Rehearsed on CPU: world 2 over gloo with the stub tile producer (`--stub-cpu`), both
+scaling forms; the sharding / gather / launcher code is exactly what the GPU run uses."""
+import json
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parents[1]
+
+
+def run(*extra, env=None):
+    e = dict(os.environ)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        e.pop(k, None)
+    e.update(env or {})
+    return subprocess.run([sys.executable, str(ROOT / "bench.py"), "--stub-cpu", "--config", "tiny", "--steps", "2", "--warmup", "1",
+                           *extra], capture_output=True, text=True, timeout=600, cwd=str(ROOT), env=e)
+
+
+@pytest.mark.parametrize("scaling,config", [("weak", "tiny"), ("strong", "tiny"), ("weak", "cfg4s"), ("strong", "cfg4s")])
+def test_self_launch_world2(scaling, config):
+    extra = ["--gpus", "2", "--scaling", scaling]
+    if config != "tiny":
+        extra += ["--config", config]
+    p = run(*extra)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == scaling and d["steps"] == 2 and d["warmup"] == 1
+    assert d["stub_frame_ok"] is True
+    n = d["config"]["rays_per_gpu_per_step"]
+    H, W = (64, 64) if config == "tiny" else (48, 60)
+    assert n == (H * W // 2 if scaling == "strong" else H * W)
+    total = H * W if scaling == "strong" else 2 * H * W
+    assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert d["unit"] == "rays/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+
+
+def test_world_mismatch_is_an_error():
+    p = run("--gpus", "2", env={"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0"})
+    assert p.returncode != 0 and "WORLD_SIZE" in (p.stderr + p.stdout)
+
+
+def test_single_process_stub():
+    p = run()
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads(p.stdout.strip())
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["stub_frame_ok"] is True

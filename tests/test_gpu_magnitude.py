@@ -1,0 +1,113 @@
+"""The default arithmetic (f16x3: fp32 operands split into fp16 hi+lo) against magnitude.
+
+fp16 has an absolute floor (subnormals, 2^-24) and a ceiling (65504; the hidden state is carried at 2^-4, so an
+activation overflows at |x| >= ~1.05e6).  Real ResNet34 latents and trained weights are not unit-scale like the
+synthetic ones, so: sweep latent scale x weight scale x bias scale, and require for every cell EITHER fp32-grade
+agreement with the exact-fp32-MFMA kernel and the CPU oracle (the same bars as tests/test_gpu_parity.py) OR a loud
+failure -- non-finite samples that `forward()` turns into a RuntimeError naming precision='fp32' -- never finite
+garbage.  The measured envelope is quoted in DESIGN.md §2."""
+import numpy as np
+import pytest
+import torch
+
+from diner_amd import synth
+from tests.test_oracle_golden import _check_rgbsigma
+
+pytestmark = pytest.mark.gpu
+
+LATENT = [0.01, 1.0, 30.0]
+WEIGHT = [0.3, 1.0, 3.0]
+BIAS = [0.0, 1.0]
+
+
+def T(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def _case(ls, ws, bs):
+    sc = synth.make_scene(24, 24, 3, seed=5, feature_padding=4, latent_scale=ls)
+    w = synth.make_mlp_weights(11, bias_scale=bs)
+    w = {k: (v * np.float32(ws) if k.endswith("weight") else v) for k, v in w.items()}
+    rays = sc.target_rays()[:, ::7]
+    return sc, w, rays
+
+
+@pytest.mark.parametrize("bs", BIAS)
+@pytest.mark.parametrize("ws", WEIGHT)
+@pytest.mark.parametrize("ls", LATENT)
+def test_f16x3_envelope(ls, ws, bs):
+    from diner_amd import NeRFRendererDGS
+    from diner_amd.model_stub import model_from_scene
+    from oracle.oracle import Oracle
+    dev = torch.device("cuda:0")
+    sc, w, rays = _case(ls, ws, bs)
+    K = 16
+    m = model_from_scene(sc, w, device=dev)
+    z = np.sort(np.random.RandomState(1).uniform(sc.near, sc.far, (1, rays.shape[1], K)).astype(np.float32), -1)
+    xyz = rays[0, :, None, :3] + z[0, ..., None] * rays[0, :, None, 3:6]
+    dirs = np.broadcast_to(rays[0, :, None, 3:6], xyz.shape)
+    ref = Oracle(sc, w).points_forward(xyz.reshape(-1, 3), dirs.reshape(-1, 3)).reshape(z.shape[1], K, 4)
+    out = {}
+    for prec in ("fp32", "f16x3"):
+        r = NeRFRendererDGS(n_samples=K, n_depth_candidates=64, n_gaussian=4, white_bkgd=True)
+        r.precision = prec
+        with torch.no_grad():
+            out[prec] = r.render_points(m, T(rays, dev), T(z, dev)).cpu().numpy()[0]
+    finite_ref = np.isfinite(ref).all()
+    if finite_ref:
+        _check_rgbsigma(out["fp32"], ref)               # the exact-fp32 kernel follows the oracle everywhere
+    f16 = out["f16x3"]
+    if np.isfinite(f16).all():
+        assert finite_ref
+        _check_rgbsigma(f16, ref)
+        _check_rgbsigma(f16, out["fp32"])
+        verdict = "fp32-grade"
+    else:
+        # outside the envelope: must be loud.  forward() raises (deferred check -> check_finite()), fp32 mode renders it.
+        r = NeRFRendererDGS(n_samples=K, n_depth_candidates=64, n_gaussian=4, white_bkgd=True)
+        with torch.no_grad():
+            r(m, T(rays, dev), z_samples=T(z, dev))
+            with pytest.raises(RuntimeError, match="precision = 'fp32'"):
+                r.check_finite()
+            r.precision = "fp32"
+            o = r(m, T(rays, dev), z_samples=T(z, dev))
+            if finite_ref:
+                r.check_finite()
+                assert bool(torch.isfinite(o.fine.rgb).all())
+        # non-finite samples are NaN/inf, never finite garbage next to a finite oracle value
+        bad = ~np.isfinite(f16).all(-1)
+        if finite_ref:
+            _check_rgbsigma(f16[~bad], ref[~bad])
+        verdict = f"LOUD ({bad.mean():.0%} of the samples non-finite)"
+    print(f"latent x{ls:g} weights x{ws:g} bias {bs:g}: sigma max {np.nanmax(ref[..., 3]):.3g} -> f16x3 {verdict}")
+
+
+def test_nonfinite_is_raised_not_returned():
+    """A latent far outside the fp16 range: f16x3 must raise through every entry (deferred, sync and render_image)."""
+    from diner_amd import NeRFRendererDGS
+    from diner_amd.model_stub import model_from_scene
+    dev = torch.device("cuda:0")
+    sc, w, rays = _case(1e7, 1.0, 0.0)
+    m = model_from_scene(sc, w, device=dev)
+    r = NeRFRendererDGS(n_samples=16, n_depth_candidates=64, n_gaussian=4)
+    with torch.no_grad():
+        r(m, T(rays, dev))                       # deferred: the call itself returns
+        torch.cuda.synchronize()
+        with pytest.raises(RuntimeError, match="inf/NaN"):
+            r(m, T(rays, dev))                   # ... the next one reports it
+        r.finite_check = "sync"
+        with pytest.raises(RuntimeError, match="inf/NaN"):
+            r(m, T(rays, dev))
+        r.finite_check = "off"
+        o = r(m, T(rays, dev))
+        assert not bool(torch.isfinite(o.fine.rgb).all())
+        r.finite_check = "deferred"
+        E = T(sc.target_extrinsics[None], dev)
+        Kt = T(sc.target_intrinsics[None], dev)
+        with pytest.raises(RuntimeError, match="inf/NaN"):
+            r.render_image(m, E, Kt, 8, 8, sc.near, sc.far)
+        # a healthy model afterwards is not blamed for the old frames
+        sc2, w2, rays2 = _case(1.0, 1.0, 0.0)
+        m2 = model_from_scene(sc2, w2, device=dev)
+        r(m2, T(rays2, dev))
+        r.check_finite()

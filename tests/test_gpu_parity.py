@@ -153,6 +153,19 @@ def test_forward_end_to_end_replayed_noise(golden, dev, precision):
     np.testing.assert_allclose(depth[ok], golden["depth"][ok], rtol=0, atol=2e-4)
     w = out.fine.weights.cpu().numpy()[0]
     assert np.all(w >= 0) and np.all(w.sum(-1) <= 1 + 1e-5)
+    # The non-firm rays: an erf-last-ulp candidate is "non-zero" or not depending on the math library, one kept sample more
+    # or less changes m and with it EVERY uniform fill-up sample of the ray (z_j = near + (j+U)(far-near)/m,
+    # nerf_renderer.py:376-396), and on these scenes' random radiance field a shifted sample set is a different integral.
+    # Not asserted to 1e-4 (the reference disagrees with itself across erf implementations there): reported, and bounded
+    # loosely so that a systematic error on these rays (the majority of surface rays at the headline parameters) would show.
+    nf = ~firm
+    if nf.any():
+        d, dd = np.abs(rgb - golden["rgb"]).max(-1)[nf], np.abs(depth - golden["depth"])[nf]
+        same = np.abs(np.sort(out.fine.weights.cpu().numpy()[0], -1) - np.sort(golden["weights"], -1)).max(-1)[nf] <= 1e-4
+        print(f"{golden.name} {precision}: non-firm rays {nf.sum()}/{nf.size}: |drgb| median {np.median(d):.2e} p90 "
+              f"{np.percentile(d, 90):.2e} max {d.max():.2e}; |ddepth| median {np.median(dd):.2e} p90 {np.percentile(dd, 90):.2e} "
+              f"max {dd.max():.2e}; rays with the golden's weights {same.mean():.2f}")
+        assert np.median(d) <= 0.05 and np.median(dd) <= 0.05 * float(golden.rays[0, 0, 7])
 
 
 def test_forward_perf_mode_properties(golden, dev):

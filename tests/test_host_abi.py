@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/diner_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == names, "ctypes table and header drifted apart"
-    assert lib.diner_version() == 1
+    assert lib.diner_version() == 2
     fp32_img = 16 * 7 * 256 + 13 * 16 * 64 * 256 + 64 * 256 + 14 * 512 + 32
     f16_img = (16 * 4 * 1024 + 13 * 16 * 32 * 1024 + 32 * 1024) // 2 + 14 * 512 + 32
     assert lib.diner_mlp_packed_floats() == fp32_img + f16_img
@@ -35,9 +35,9 @@ def test_argument_validation_returns_codes():
     from diner_amd import _lib
     lib = _lib.lib()
     # NULL pointers / bad sizes are rejected before any launch (no GPU is touched)
-    assert lib.diner_composite(None, None, None, 4, 8, 1, None, None, None, None) == -1
+    assert lib.diner_composite(None, None, None, 4, 8, 1, None, None, None, None, None) == -1
     assert b"NULL" in lib.diner_last_error()
-    assert lib.diner_composite(None, None, None, -1, 8, 1, None, None, None, None) == -1
+    assert lib.diner_composite(None, None, None, -1, 8, 1, None, None, None, None, None) == -1
     assert lib.diner_sample_coarse(None, 3, 0, None, 0, None, None) == -1
     assert lib.diner_pack_latent(None, 1, 512, 4, 4, None, None) == -1
     cfg = _lib.DinerSamplerCfg(10, 4, 5, 0.05)  # n_gaussian > n_samples (nerf_renderer.py:89)
