@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Generates diner_amd/csrc/f16_core.inc: the assembly-level GEMM core of points_mlp_f16.hip.
+
+    python3 diner_amd/csrc/gen_f16_core.py [RING] > diner_amd/csrc/f16_core.inc      (the Makefile does this)
+
+Why a generator: the fused point/MLP kernel keeps its whole hidden state in registers, and hipcc's
+allocation of that 256-register kernel decided its speed (round 1: 147 spilled VGPRs, every
+restructuring attempt ended in 400+).  The core therefore owns its registers.  The kernel is built with
+__attribute__((amdgpu_num_vgpr(CAP))), CAP = 256 - 128 - 16*RING: hipcc allocates v0..v[CAP-1] only and treats every
+higher VGPR as reserved, and exactly those are the core's (named literally; the clobber lists make the kernel
+descriptor allocate them):
+
+  v[CAP   : CAP+63]    x    accumulator grid of this wave (64 features x 64 points, 4 tiles of 32x32)
+  v[CAP+64: CAP+127]   net  second accumulator grid (the residual block's inner activation)
+  v[CAP+128: 255]      the weight ring: RING k-blocks x (2 feature tiles x hi/lo) fragments, written by
+                       global_load and read by the MFMAs as their A operand -- it stays in flight across
+                       barriers, layers and the compiler's glue code
+  v0..v[CAP-1]         the activation fragments (two buffers) and addresses, as ordinary asm temporaries
+(A first version kept these in AGPRs; hipcc then used the same AGPRs as spill space and even as load destinations
+between the asm statements.  tests/test_isa_guard.py checks on the generated ISA that the compiler stays below CAP,
+uses no AGPR and no scratch.)
+
+One statement = one layer for one wave:   s_waitcnt lgkmcnt(0); s_barrier; G1; s_barrier; G2; s_barrier
+  G1 = k-blocks of LDS region 0 (k <  256: the operand rows written by waves 0-3)
+  G2 = k-blocks of LDS region 1 (k >= 256: written by waves 4-7)
+The three barriers per layer are what the half-layer stagger of the two wave groups is built on
+(points_mlp_f16.hip, "schedule").
+
+Per k-block (16 k): 4 fragment loads of 16 B per lane from L2 (RING-1 k-blocks ahead; at the end of a
+layer they run on into the NEXT layer's first k-blocks, so the ring never drains), 4 ds_read_b128 (the next
+k-block's activation fragments, one ahead), counted waits, 12 MFMAs (v_mfma_f32_32x32x16_f16; per product
+W_lo*a_hi, W_hi*a_lo, W_hi*a_hi: small terms first).
+
+Weight stream of one (wave, feature tile): contiguous over k-blocks, 2 KiB per k-block: [hi 64 lanes x 16 B | lo].
+LDS operand image (bytes): unit-row u = k/8 holds rows (points) 0..63 x 16 B: hi at u*2048, lo at
+u*2048 + 1024.  Lane (r = lane&31, hh = lane>>5) reads for k-block kb: u = 2*kb + hh, point r (+32).
+"""
+import sys
+
+CAP = 96                                        # set by main(): 256 - 128 - 16 * RING
+X_OFF, NET_OFF, RING_OFF = 0, 64, 128           # relative to CAP
+
+
+def acc(base, tn, tp):
+    lo = CAP + base + 16 * (2 * tn + tp)
+    return f"v[{lo}:{lo + 15}]"
+
+
+def ring(slot, tn, part):  # part 0 = hi, 1 = lo
+    lo = CAP + RING_OFF + 16 * slot + 8 * tn + 4 * part
+    return f"v[{lo}:{lo + 3}]"
+
+
+class Block:
+    noload = False   # probe-only ablation: the MFMAs read whatever the ring holds, no weight stream
+
+    def __init__(self, name, acc_base, nkb1, nkb2, D):
+        assert D in (2, 4) and nkb1 % D == 0 and nkb2 % D == 0 and nkb1 > 0
+        self.name, self.base, self.nkb1, self.nkb2, self.D = name, acc_base, nkb1, nkb2, D
+        self.lines = []
+        self.nlabel = 0
+
+    def e(self, s):
+        self.lines.append(s)
+
+    def loads(self, slot):
+        """the 4 fragment loads of one k-block into ring slot `slot`; the lane offset then moves on one k-block"""
+        for tn, w in ((0, "%[w0]"), (1, "%[w1]")):
+            if self.noload:
+                continue
+            self.e(f"global_load_dwordx4 {ring(slot, tn, 0)}, %[voff], {w}")
+            self.e(f"global_load_dwordx4 {ring(slot, tn, 1)}, %[voff], {w} offset:1024")
+        self.e("v_add_u32 %[voff], 2048, %[voff]")
+
+    def switch_to_next(self):
+        self.e("s_mov_b64 %[w0], %[nw0]")
+        self.e("s_mov_b64 %[w1], %[nw1]")
+        self.e("v_mov_b32 %[voff], %[loff]")
+
+    def frag_reads(self, buf, imm):
+        # order: hi tp0, hi tp1, lo tp0, lo tp1
+        for i in range(4):
+            self.e(f"ds_read_b128 %[f{buf}{i}], %[ab] offset:{imm + 512 * i}")
+
+    def mfmas(self, slot, buf):
+        b = self.base
+        hi = [f"%[f{buf}0]", f"%[f{buf}1]"]
+        lo = [f"%[f{buf}2]", f"%[f{buf}3]"]
+        for wpart, frags in ((1, hi), (0, lo), (0, hi)):   # W_lo*a_hi, W_hi*a_lo, W_hi*a_hi
+            for tn in range(2):
+                for tp in range(2):
+                    self.e(f"v_mfma_f32_32x32x16_f16 {acc(b, tn, tp)}, {ring(slot, tn, wpart)}, {frags[tp]}, {acc(b, tn, tp)}")
+
+    def body(self, tail, switch):
+        """D consecutive k-blocks: k-block j of the iteration consumes ring slot j and fragment buffer j & 1 (D is even).
+        tail = the half's last iteration (its last k-block prefetches no fragments); switch = the layer's last
+        iteration (after its first load group the weight stream moves on to the next layer)."""
+        D = self.D
+        for j in range(D):
+            self.loads((j + D - 1) % D)                              # k-block kb + D - 1
+            if switch and j == 0:
+                self.switch_to_next()
+            if j < D - 1:
+                self.frag_reads((j + 1) & 1, (j + 1) * 4096)
+                pending = 4
+            elif not tail:
+                self.e(f"v_add_u32 %[ab], {D * 4096}, %[ab]")       # the next iteration's first k-block
+                self.frag_reads((j + 1) & 1, 0)
+                pending = 4
+            else:
+                pending = 0
+            self.e(f"s_waitcnt vmcnt({4 * (D - 1)})")                # this k-block's weights: all but the D-1 younger groups
+            self.e(f"s_waitcnt lgkmcnt({pending})")                  # this k-block's fragments
+            self.mfmas(j, j & 1)
+
+    def half(self, nkb, region, last_half):
+        iters = nkb // self.D
+        self.e(f"v_add_u32 %[ab], {65536 * region}, %[ab0]")
+        self.frag_reads(0, 0)                                        # the half's first k-block, behind the barrier
+        if iters > 1:
+            lbl = f"L{self.nlabel}_%="
+            self.nlabel += 1
+            self.e(f"s_mov_b32 %[cnt], {iters - 1}")
+            self.e(f"{lbl}:")
+            self.body(tail=False, switch=False)
+            self.e("s_sub_u32 %[cnt], %[cnt], 1")
+            self.e("s_cmp_lg_u32 %[cnt], 0")
+            self.e(f"s_cbranch_scc1 {lbl}")
+        self.body(tail=True, switch=last_half)
+
+    def emit(self):
+        D = self.D
+        self.e(f"v_add_u32 %[voff], {(D - 1) * 2048}, %[loff]")      # k-blocks 0..D-2 of this layer are already in the ring
+        self.e("s_waitcnt lgkmcnt(0)")                                # this wave's operand stores (its S phase) have landed
+        self.e("s_barrier")
+        self.half(self.nkb1, 0, last_half=(self.nkb2 == 0))
+        self.e("s_barrier")
+        if self.nkb2:
+            self.half(self.nkb2, 1, last_half=True)
+        self.e("s_nop 15")                                            # MFMA results -> VALU reads in the glue (XDL write -> VALU read wait states)
+        self.e("s_nop 7")
+        self.e("s_barrier")
+        return self.lines
+
+
+def clobbers(D):
+    return ", ".join(f'"v{i}"' for i in range(CAP, 256))
+
+
+def asm_body(lines):
+    return "\n".join(f'        "{l}\\n"' for l in lines)
+
+
+def cxx(block):
+    lines = block.emit()
+    frag_ops = ", ".join(f'[f{b}{i}] "=&v"(f{b}{i})' for b in range(2) for i in range(4))
+    return f"""
+// {block.name}: accumulators v[{CAP + block.base}:{CAP + block.base + 63}], {block.nkb1} + {block.nkb2} k-blocks, ring depth {block.D}
+// w0/w1: this wave's weight streams (feature tile 0/1) of THIS layer; nw0/nw1: of the layer executed next
+__device__ __forceinline__ void {block.name}(uint64_t w0, uint64_t w1, uint64_t nw0, uint64_t nw1, unsigned loff, unsigned ab0)
+{{
+    h8 f00, f01, f02, f03, f10, f11, f12, f13;
+    unsigned ab, voff, cnt;
+    asm volatile(
+{asm_body(lines)}
+        : {frag_ops}, [ab] "=&v"(ab), [voff] "=&v"(voff), [cnt] "=&s"(cnt), [w0] "+s"(w0), [w1] "+s"(w1)
+        : [nw0] "s"(nw0), [nw1] "s"(nw1), [loff] "v"(loff), [ab0] "v"(ab0)
+        : "memory", "scc", {clobbers(block.D)});
+}}
+"""
+
+
+def prologue(D):
+    """Fill the ring with k-blocks 0..D-2 of the first layer (once per kernel; afterwards every layer block
+    prefetches its successor's first k-blocks)."""
+    b = Block("prologue", 0, D, 0, D)
+    b.e("v_mov_b32 %[voff], %[loff]")
+    keep, b.noload = b.noload, False
+    for j in range(D if keep else D - 1):                # the no-load ablation still starts from real weights in every slot
+        b.loads(j)
+    return f"""
+__device__ __forceinline__ void ring_prologue(uint64_t w0, uint64_t w1, unsigned loff)
+{{
+    unsigned voff;
+    asm volatile(
+{asm_body(b.lines)}
+        : [voff] "=&v"(voff)
+        : [w0] "s"(w0), [w1] "s"(w1), [loff] "v"(loff)
+        : "memory", {clobbers(D)});
+}}
+"""
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    D = int(args[0]) if args else 4
+    ns = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--ns=")), None)
+    Block.noload = "--noload" in sys.argv
+    global CAP
+    CAP = 256 - 128 - 16 * D
+    out = [f"""// GENERATED by gen_f16_core.py (ring depth {D}{", no weight loads: ablation" if Block.noload else ""}) -- do not edit; see the generator for the design.
+{"namespace " + ns + " {" if ns else "#pragma once"}
+constexpr int F16_RING = {D};
+constexpr int F16_VGPR_CAP = {CAP};   // hipcc's share (amdgpu_num_vgpr); the core owns v[{CAP}:255]
+constexpr int F16_X = {CAP + X_OFF}, F16_NET = {CAP + NET_OFF};   // first register of the two accumulator grids
+"""]
+    out.append(prologue(D))
+    out.append(cxx(Block("layer_x_full", X_OFF, 16, 16, D)))
+    out.append(cxx(Block("layer_net_full", NET_OFF, 16, 16, D)))
+    out.append(cxx(Block("layer_x_in", X_OFF, 4, 0, D)))
+    if ns:
+        out.append("}  // namespace " + ns + "\n")
+    sys.stdout.write("\n".join(out))
+
+
+if __name__ == "__main__":
+    main()
