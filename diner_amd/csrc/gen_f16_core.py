@@ -54,9 +54,10 @@ def ring(slot, tn, part):  # part 0 = hi, 1 = lo
 class Block:
     noload = False   # probe-only ablation: the MFMAs read whatever the ring holds, no weight stream
 
-    def __init__(self, name, acc_base, nkb1, nkb2, D):
+    def __init__(self, name, acc_base, nkb1, nkb2, D, region1_off=65536):
         assert D in (2, 4) and nkb1 % D == 0 and nkb2 % D == 0 and nkb1 > 0
         self.name, self.base, self.nkb1, self.nkb2, self.D = name, acc_base, nkb1, nkb2, D
+        self.region1_off = region1_off     # byte offset of the operand rows written by waves 4-7 (k >= 16 * nkb1)
         self.lines = []
         self.nlabel = 0
 
@@ -115,7 +116,7 @@ class Block:
 
     def half(self, nkb, region, last_half):
         iters = nkb // self.D
-        self.e(f"v_add_u32 %[ab], {65536 * region}, %[ab0]")
+        self.e(f"v_add_u32 %[ab], {self.region1_off * region}, %[ab0]")
         self.frag_reads(0, 0)                                        # the half's first k-block, behind the barrier
         if iters > 1:
             lbl = f"L{self.nlabel}_%="
@@ -170,6 +171,67 @@ __device__ __forceinline__ void {block.name}(uint64_t w0, uint64_t w1, uint64_t 
 """
 
 
+def gather_cxx(D, GQ=4):
+    """x += bilerp(G)(uv) for this wave's 64 features x 64 points (resnetfc.py:152-153 with lin_z hoisted to feature maps):
+    64 float4 loads per lane (4 taps x 2 point tiles x 2 feature tiles x 4 register groups), landing in the `net` grid's
+    registers, which are dead between a block's fc_1 operand store and the next fc_0's bias init: 16 float4 slots = 4 quads
+    (a quad = the 4 taps of one (tp, tn, g)) in flight.  gather_issue() starts the first 4 quads one layer EARLY (they land while
+    the preceding GEMM runs); gather_finish() consumes quad after quad with counted waits, re-issuing into the freed slots."""
+    NQ = 16
+
+    def quad(q):
+        return q // 8, (q // 4) % 2, q % 4          # tp, tn, g
+
+    def slot(q, tap):
+        lo = CAP + NET_OFF + 16 * (q % GQ) + 4 * tap
+        return lo
+
+    def issue(q):
+        tp, tn, g = quad(q)
+        return [f"global_load_dwordx4 v[{slot(q, t)}:{slot(q, t) + 3}], %[o{tp}{t}], %[G] offset:{tn * 128 + g * 32}" for t in range(4)]
+
+    first = [l for q in range(GQ) for l in issue(q)]
+    fin = []
+    for q in range(NQ):
+        # behind the early quads sit the ring's prefetch (4 (D-1) loads) and possibly glue loads: allowing 12 + 4 (D-1) younger
+        # operations is exact without glue loads and merely stricter with them (in-order return)
+        younger = 4 * (GQ - 1) + 4 * (D - 1) if q < GQ else 4 * min(GQ - 1, NQ - 1 - q)
+        fin.append(f"s_waitcnt vmcnt({younger})")
+        tp, tn, g = quad(q)
+        xr = CAP + X_OFF + 16 * (2 * tn + tp) + 4 * g
+        for j in range(4):
+            fin.append(f"v_mul_f32 %[t{j}], v{slot(q, 0) + j}, %[w{tp}0]")
+        for t in range(1, 4):
+            for j in range(4):
+                fin.append(f"v_fmac_f32 %[t{j}], v{slot(q, t) + j}, %[w{tp}{t}]")
+        for j in range(4):
+            fin.append(f"v_add_f32 v{xr + j}, v{xr + j}, %[t{j}]")
+        if q + GQ < NQ:
+            fin += issue(q + GQ)
+    offs = ", ".join(f'[o{tp}{t}] "v"(ob[{tp}][{t}])' for tp in range(2) for t in range(4))
+    wts = ", ".join(f'[w{tp}{t}] "v"(wt[{tp}][{t}])' for tp in range(2) for t in range(4))
+    return f"""
+// x += bilerp(G)(uv): ob[tp][tap] = byte offset of this lane's first float4 in the tap's texel, wt[tp][tap] = its weight
+__device__ __forceinline__ void gather_issue(uint64_t G, const unsigned (&ob)[2][4])
+{{
+    asm volatile(
+{asm_body(first)}
+        :
+        : [G] "s"(G), {offs}
+        : "memory", {clobbers(0)});
+}}
+__device__ __forceinline__ void gather_finish(uint64_t G, const unsigned (&ob)[2][4], const float (&wt)[2][4])
+{{
+    float t0, t1, t2, t3;
+    asm volatile(
+{asm_body(fin)}
+        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
+        : [G] "s"(G), {offs}, {wts}
+        : "memory", {clobbers(0)});
+}}
+"""
+
+
 def prologue(D):
     """Fill the ring with k-blocks 0..D-2 of the first layer (once per kernel; afterwards every layer block
     prefetches its successor's first k-blocks)."""
@@ -207,7 +269,10 @@ constexpr int F16_X = {CAP + X_OFF}, F16_NET = {CAP + NET_OFF};   // first regis
     out.append(prologue(D))
     out.append(cxx(Block("layer_x_full", X_OFF, 16, 16, D)))
     out.append(cxx(Block("layer_net_full", NET_OFF, 16, 16, D)))
-    out.append(cxx(Block("layer_x_in", X_OFF, 4, 0, D)))
+    # lin_in: 64 inputs = 4 k-blocks; waves 0-3 write unit-rows 0-3 (k < 32), waves 4-7 unit-rows 4-7 (8 KiB further)
+    out.append(cxx(Block("layer_x_in", X_OFF, 2, 2, D, region1_off=8192)))
+    GQ = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--gq=')), 4)
+    out.append(gather_cxx(D, GQ))
     if ns:
         out.append("}  // namespace " + ns + "\n")
     sys.stdout.write("\n".join(out))
