@@ -38,6 +38,7 @@ u*2048 + 1024.  Lane (r = lane&31, hh = lane>>5) reads for k-block kb: u = 2*kb 
 import sys
 
 CAP = 96                                        # set by main(): 256 - 128 - 16 * RING
+PRIO = 0                                        # --prio=N: s_setprio N for the S phases, 0 inside the layer blocks
 X_OFF, NET_OFF, RING_OFF = 0, 64, 128           # relative to CAP
 
 
@@ -132,6 +133,8 @@ class Block:
     def emit(self):
         D = self.D
         self.e(f"v_add_u32 %[voff], {(D - 1) * 2048}, %[loff]")      # k-blocks 0..D-2 of this layer are already in the ring
+        if PRIO:
+            self.e("s_setprio 0")                                     # GEMM at low priority: the partner's S phase (VALU, LDS, gather) goes first
         self.e("s_waitcnt lgkmcnt(0)")                                # this wave's operand stores (its S phase) have landed
         self.e("s_barrier")
         self.half(self.nkb1, 0, last_half=(self.nkb2 == 0))
@@ -141,6 +144,8 @@ class Block:
         self.e("s_nop 15")                                            # MFMA results -> VALU reads in the glue (XDL write -> VALU read wait states)
         self.e("s_nop 7")
         self.e("s_barrier")
+        if PRIO:
+            self.e(f"s_setprio {PRIO}")                               # the glue code that follows (this wave's S phase) outranks the partner's MFMAs
         return self.lines
 
 
@@ -258,10 +263,12 @@ def main():
     D = int(args[0]) if args else 4
     ns = next((a.split("=", 1)[1] for a in sys.argv[1:] if a.startswith("--ns=")), None)
     Block.noload = "--noload" in sys.argv
-    global CAP
+    global CAP, PRIO
     CAP = 256 - 128 - 16 * D
+    PRIO = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--prio=')), 0)
     out = [f"""// GENERATED by gen_f16_core.py (ring depth {D}{", no weight loads: ablation" if Block.noload else ""}) -- do not edit; see the generator for the design.
 {"namespace " + ns + " {" if ns else "#pragma once"}
+// generator arguments: {" ".join(sys.argv[1:])}
 constexpr int F16_RING = {D};
 constexpr int F16_VGPR_CAP = {CAP};   // hipcc's share (amdgpu_num_vgpr); the core owns v[{CAP}:255]
 constexpr int F16_X = {CAP + X_OFF}, F16_NET = {CAP + NET_OFF};   // first register of the two accumulator grids

@@ -35,8 +35,8 @@ def _cap():
 def test_generated_core_is_current():
     """f16_core.inc in the tree is what the generator produces (the Makefile regenerates it; the file is committed so that
     the kernel source reads complete)."""
-    ring = re.search(r"constexpr int F16_RING = (\d+);", (CSRC / "f16_core.inc").read_text()).group(1)
-    out = subprocess.run(["python3", str(CSRC / "gen_f16_core.py"), ring], check=True, capture_output=True, text=True).stdout
+    args = re.search(r"// generator arguments: (.*)", (CSRC / "f16_core.inc").read_text()).group(1).split()
+    out = subprocess.run(["python3", str(CSRC / "gen_f16_core.py"), *args], check=True, capture_output=True, text=True).stdout
     assert out == (CSRC / "f16_core.inc").read_text()
 
 
