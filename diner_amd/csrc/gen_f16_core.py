@@ -176,62 +176,119 @@ __device__ __forceinline__ void {block.name}(uint64_t w0, uint64_t w1, uint64_t 
 """
 
 
-def gather_cxx(D, GQ=4):
-    """x += bilerp(G)(uv) for this wave's 64 features x 64 points (resnetfc.py:152-153 with lin_z hoisted to feature maps):
-    64 float4 loads per lane (4 taps x 2 point tiles x 2 feature tiles x 4 register groups), landing in the `net` grid's
-    registers, which are dead between a block's fc_1 operand store and the next fc_0's bias init: 16 float4 slots = 4 quads
-    (a quad = the 4 taps of one (tp, tn, g)) in flight.  gather_issue() starts the first 4 quads one layer EARLY (they land while
-    the preceding GEMM runs); gather_finish() consumes quad after quad with counted waits, re-issuing into the freed slots."""
-    NQ = 16
+def gather_cxx(D, GQ=3):
+    """x += bilerp(G)(uv) for this wave's 64 features x 64 points (resnetfc.py:152-153 with lin_z hoisted to feature maps).
 
-    def quad(q):
-        return q // 8, (q // 4) % 2, q % 4          # tp, tn, g
+    The accumulator layout has the POINT on the lane, so a gather straight into it makes every 4-lane step of a load touch 4
+    different cache lines: 64 tag look-ups per instruction, and the CU's texture addresser, not latency, bounded the phase
+    (2 and 4 quads in flight took the same time).  So the loads are COALESCED instead -- lane = (point of a group of 4, float4 of the
+    wave's 256-byte feature slice): 16 lanes read one texel slice contiguously -- the 4 taps are blended in that layout, and the
+    result goes through LDS to the accumulator layout: the staging area is this wave's own 8 unit-rows of the operand image
+    (16 KiB = 64 points x 256 B), which are dead between the barrier that ends the previous layer and this wave's operand store;
+    float4 q of point p sits at p*256 + ((q ^ (p & 15)) * 16): conflict-free for the coalesced writes and the transposed reads.
 
-    def slot(q, tap):
-        lo = CAP + NET_OFF + 16 * (q % GQ) + 4 * tap
-        return lo
+    Loads land in the `net` grid's registers (dead between a block's fc_1 operand store and the next fc_0's bias init): GQ = 3 groups
+    (a group = 4 points x 4 taps = 4 float4 per lane) in flight, the grid's last 16 registers are the routine's float4 temporaries.
+    gather_issue() starts the first GQ groups one layer EARLY (they land while the preceding GEMM runs); gather_finish() consumes
+    group after group with counted waits, re-issuing into the freed slots.
+    Footprint table in LDS (written once per view): per point 4 x u32 byte offsets of the tap texels, 4 x f32 weights."""
+    assert GQ == 3
+    NG = 16
+    NETB = CAP + NET_OFF
+    TO, TW, TT, RD = NETB + 48, NETB + 52, NETB + 56, NETB + 60      # float4 temporaries
 
-    def issue(q):
-        tp, tn, g = quad(q)
-        return [f"global_load_dwordx4 v[{slot(q, t)}:{slot(q, t) + 3}], %[o{tp}{t}], %[G] offset:{tn * 128 + g * 32}" for t in range(4)]
+    def q4(r):
+        return f"v[{r}:{r + 3}]"
 
-    first = [l for q in range(GQ) for l in issue(q)]
-    fin = []
-    for q in range(NQ):
-        # behind the early quads sit the ring's prefetch (4 (D-1) loads) and possibly glue loads: allowing 12 + 4 (D-1) younger
-        # operations is exact without glue loads and merely stricter with them (in-order return)
-        younger = 4 * (GQ - 1) + 4 * (D - 1) if q < GQ else 4 * min(GQ - 1, NQ - 1 - q)
-        fin.append(f"s_waitcnt vmcnt({younger})")
-        tp, tn, g = quad(q)
-        xr = CAP + X_OFF + 16 * (2 * tn + tp) + 4 * g
+    def slot(i, tap):
+        return NETB + 16 * (i % GQ) + 4 * tap
+
+    def taps_read(i, which):          # offsets (which = 0) or weights (1) of this lane's point of group i
+        return f"ds_read_b128 {q4(TO if which == 0 else TW)}, %[tbase] offset:{i * 128 + 16 * which}"
+
+    def issue(i):
+        """the byte offsets of group i's taps are in TO"""
+        out = [f"v_add_u32 %[a{t}], %[qb], v{TO + t}" for t in range(4)]
+        out += [f"global_load_dwordx4 {q4(slot(i, t))}, %[a{t}], %[G]" for t in range(4)]
+        return out
+
+    # ---- early issue: groups 0..GQ-1
+    first = []
+    for i in range(GQ):
+        first.append(taps_read(i, 0))
+        first.append("s_waitcnt lgkmcnt(0)")
+        first += issue(i)
+    # ---- finish (early = the first GQ groups were issued before the preceding layer block: the ring's prefetch sits behind them)
+    def finish(early):
+      fin = [] if early else list(first)
+      for i in range(NG):
+        fin.append(taps_read(i, 1))                                  # this group's weights
+        nxt = i + GQ < NG
+        if nxt:
+            fin.append(taps_read(i + GQ, 0))                          # offsets of the group that goes into the slot freed below
+        gap = 4 * (D - 1) if early else 0                             # the ring's prefetch, issued between the early groups and the rest
+        younger = 4 * (GQ - 1) + gap if i < GQ else 4 * min(GQ - 1, NG - 1 - i)
+        fin.append(f"s_waitcnt vmcnt({younger})")                     # exact, or stricter when glue loads are outstanding; never weaker
+        fin.append(f"s_waitcnt lgkmcnt({1 if nxt else 0})")           # the weights have landed (LDS returns in order)
         for j in range(4):
-            fin.append(f"v_mul_f32 %[t{j}], v{slot(q, 0) + j}, %[w{tp}0]")
+            fin.append(f"v_mul_f32 v{TT + j}, v{slot(i, 0) + j}, v{TW}")
         for t in range(1, 4):
             for j in range(4):
-                fin.append(f"v_fmac_f32 %[t{j}], v{slot(q, t) + j}, %[w{tp}{t}]")
-        for j in range(4):
-            fin.append(f"v_add_f32 v{xr + j}, v{xr + j}, %[t{j}]")
-        if q + GQ < NQ:
-            fin += issue(q + GQ)
-    offs = ", ".join(f'[o{tp}{t}] "v"(ob[{tp}][{t}])' for tp in range(2) for t in range(4))
-    wts = ", ".join(f'[w{tp}{t}] "v"(wt[{tp}][{t}])' for tp in range(2) for t in range(4))
+                fin.append(f"v_fmac_f32 v{TT + j}, v{slot(i, t) + j}, v{TW + t}")
+        if nxt:
+            fin.append("s_waitcnt lgkmcnt(0)")                        # the next group's offsets
+            fin += issue(i + GQ)
+        fin.append(f"ds_write_b128 %[sw{i % 4}], {q4(TT)} offset:{i * 1024}")
+        fin.append("s_nop 1")                                         # TT is rewritten by the next group's first v_mul: the store must have read it
+      # ---- read back in the accumulator layout and add
+      fin.append("s_waitcnt lgkmcnt(0)")
+      for tn in range(2):
+        for g in range(4):
+            K = tn * 8 + 2 * g
+            fin.append(f"v_xor_b32 %[a0], {K}, %[hp]")
+            fin.append("v_lshl_add_u32 %[a0], %[a0], 4, %[rb]")
+            fin.append(f"ds_read_b128 {q4(TT)}, %[a0]")
+            fin.append(f"ds_read_b128 {q4(RD)}, %[a0] offset:8192")
+            fin.append("s_waitcnt lgkmcnt(0)")
+            for tp, src in ((0, TT), (1, RD)):
+                xr = CAP + X_OFF + 16 * (2 * tn + tp) + 4 * g
+                for j in range(4):
+                    fin.append(f"v_add_f32 v{xr + j}, v{xr + j}, v{src + j}")
+      return fin
     return f"""
-// x += bilerp(G)(uv): ob[tp][tap] = byte offset of this lane's first float4 in the tap's texel, wt[tp][tap] = its weight
-__device__ __forceinline__ void gather_issue(uint64_t G, const unsigned (&ob)[2][4])
+// x += bilerp(G)(uv), coalesced.  tbase = LDS address of the footprint table + 32 * (lane >> 4); qb = wave * 256 + (lane & 15) * 16;
+// sw[k] = staging write address of this lane for the groups i with i % 4 == k (the group's i * 1024 goes into the instruction);
+// rb = staging row of point c (point 32 + c: 8192 further); hp = h ^ (c & 15)
+struct GatherRegs {{ unsigned tbase, qb, sw[4], rb, hp; }};
+__device__ __forceinline__ void gather_issue(uint64_t G, const GatherRegs &r)
 {{
+    unsigned a0, a1, a2, a3;
     asm volatile(
 {asm_body(first)}
-        :
-        : [G] "s"(G), {offs}
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
+        : [G] "s"(G), [tbase] "v"(r.tbase), [qb] "v"(r.qb)
         : "memory", {clobbers(0)});
 }}
-__device__ __forceinline__ void gather_finish(uint64_t G, const unsigned (&ob)[2][4], const float (&wt)[2][4])
+// EARLY: gather_issue() ran before the preceding layer block; otherwise the whole gather happens here
+template <bool EARLY> __device__ __forceinline__ void gather_finish(uint64_t G, const GatherRegs &r);
+template <> __device__ __forceinline__ void gather_finish<false>(uint64_t G, const GatherRegs &r)
 {{
-    float t0, t1, t2, t3;
+    unsigned a0, a1, a2, a3;
     asm volatile(
-{asm_body(fin)}
-        : [t0] "=&v"(t0), [t1] "=&v"(t1), [t2] "=&v"(t2), [t3] "=&v"(t3)
-        : [G] "s"(G), {offs}, {wts}
+{asm_body(finish(False))}
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
+        : [G] "s"(G), [tbase] "v"(r.tbase), [qb] "v"(r.qb), [sw0] "v"(r.sw[0]), [sw1] "v"(r.sw[1]), [sw2] "v"(r.sw[2]), [sw3] "v"(r.sw[3]),
+          [rb] "v"(r.rb), [hp] "v"(r.hp)
+        : "memory", {clobbers(0)});
+}}
+template <> __device__ __forceinline__ void gather_finish<true>(uint64_t G, const GatherRegs &r)
+{{
+    unsigned a0, a1, a2, a3;
+    asm volatile(
+{asm_body(finish(True))}
+        : [a0] "=&v"(a0), [a1] "=&v"(a1), [a2] "=&v"(a2), [a3] "=&v"(a3)
+        : [G] "s"(G), [tbase] "v"(r.tbase), [qb] "v"(r.qb), [sw0] "v"(r.sw[0]), [sw1] "v"(r.sw[1]), [sw2] "v"(r.sw[2]), [sw3] "v"(r.sw[3]),
+          [rb] "v"(r.rb), [hp] "v"(r.hp)
         : "memory", {clobbers(0)});
 }}
 """
@@ -278,8 +335,7 @@ constexpr int F16_X = {CAP + X_OFF}, F16_NET = {CAP + NET_OFF};   // first regis
     out.append(cxx(Block("layer_net_full", NET_OFF, 16, 16, D)))
     # lin_in: 64 inputs = 4 k-blocks; waves 0-3 write unit-rows 0-3 (k < 32), waves 4-7 unit-rows 4-7 (8 KiB further)
     out.append(cxx(Block("layer_x_in", X_OFF, 2, 2, D, region1_off=8192)))
-    GQ = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--gq=')), 4)
-    out.append(gather_cxx(D, GQ))
+    out.append(gather_cxx(D))
     if ns:
         out.append("}  // namespace " + ns + "\n")
     sys.stdout.write("\n".join(out))

@@ -47,6 +47,11 @@ h, w = sc.latent_hw
 latent = torch.randn((1, NV, 512, h, w), generator=torch.Generator(device=dev).manual_seed(1234), device=dev)
 m = model_from_scene(sc, synth.make_mlp_weights(7, bias_scale=0.1), device=dev, latent=latent)
 r = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G)
-rays = torch.from_numpy(sc.target_rays()).to(dev)[:, :65536]
+rays = torch.from_numpy(sc.target_rays()).to(dev)
+import time
 with torch.no_grad():
     r(m, rays); torch.cuda.synchronize()
+    r.stage_events = []
+    r(m, rays); torch.cuda.synchronize()
+    e = r.stage_events[0]
+    print("point/MLP kernel, full frame: %.1f ms" % e[1].elapsed_time(e[2]), file=sys.stderr)
