@@ -107,6 +107,8 @@ class NeRFRendererDGS(torch.nn.Module):
         # commute; diner_pack_linz_maps).  Costs 3x the latent's memory per encode(); set False to keep
         # lin_z as per-point GEMMs.
         self.linz_maps = True
+        # informational (bench.py's executed-FLOP count): the f16x3 kernel applies block 2's fc_1 once to the mean over views
+        self.fc1_on_mean = True
         self._mlp_key = None
         self._mlp_pack = None
         self._latent_gen = self._mlp_gen = 0         # bumped by every re-pack; the lin_z maps depend on both
