@@ -187,7 +187,7 @@ def main(argv=None):
     import numpy as np
     import torch
     sys.path.insert(0, str(ROOT))
-    from diner_amd import synth
+    from synthetic import synth
     from diner_amd.dist import all_gather_tiles, shard_bounds
 
     rank = int(os.environ.get("RANK", "0"))
@@ -221,7 +221,7 @@ def main(argv=None):
     rend = model = latent = weights = None
     if not stub:
         from diner_amd import NeRFRendererDGS
-        from diner_amd.model_stub import model_from_scene
+        from synthetic.model_stub import model_from_scene
         gen = torch.Generator(device=dev).manual_seed(1234)
         latent = torch.randn((1, NV, 512, h, w), generator=gen, device=dev, dtype=torch.float32)
         weights = synth.make_mlp_weights(7, bias_scale=0.1)  # seed with sigma > 0 almost everywhere: a meaningful parity sample

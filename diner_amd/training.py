@@ -11,6 +11,7 @@ layer's input, and a hand-written backward producing gradients for the fusion-ML
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 
@@ -63,6 +64,23 @@ def split_panel(W, transpose, prec):
     check(_lib.lib().diner_train_split_panel(_p(W), K, W.stride(0), int(transpose), EXP_W, _p(planes[0]), _p(planes[1]), _st(W.device)),
           "diner_train_split_panel")
     return planes
+
+
+class PanelCache:
+    """fp16 hi/lo panels of the MLP weights, kept per (parameter object, ``_version``, orientation): re-split only after an
+    optimizer step (or any other in-place update) -- gradient accumulation / several renders per step reuse them.  Weak
+    references: the cache keeps no parameter alive and a new tensor at a recycled address is a different object."""
+
+    def __init__(self):
+        self._e = {}
+
+    def get(self, key, src, W, transpose, prec):
+        ent = self._e.get((key, transpose))
+        if ent is not None and ent[0]() is src and ent[1] == src._version and ent[2] == prec:
+            return ent[3]
+        planes = split_panel(W, transpose, prec)
+        self._e[(key, transpose)] = (weakref.ref(src), src._version, prec, planes)
+        return planes
 
 
 def _panel(A, planes, bias, S, addend, out, relu_a, amax, exp_a):
@@ -141,13 +159,18 @@ class _RenderFn(torch.autograd.Function):
         lat_nhwc = torch.empty((SBl, NVl, hl, wl, Cl), dtype=torch.float32, device=dev)   # coalesced texel reads for the gather
         check(L.diner_pack_latent(_p(lat), SBl * NVl, Cl, hl, wl, _p(lat_nhwc), st), "diner_pack_latent")
         prm = [p.detach().to(torch.float32).contiguous() for p in params]
+        # backward() re-reads these tensors (they alias the live parameters): remember their versions, as
+        # ctx.save_for_backward would, so that an in-place update between forward and backward is an error instead of a
+        # silently wrong dX (optimizer.step / EMA copy_ under gradient accumulation)
+        ctx.versions = [(weakref.ref(p), p._version) for p in params] + [(weakref.ref(latent), latent._version)]
         w_in56 = torch.zeros((HID, 56), dtype=torch.float32, device=dev)
         w_in56[:, :55] = prm[0]
         rgbsigma = f(SB, NR, K, 4)
         prec = _lib.PRECISIONS[renderer.precision]
         saved = []
-        wp = {i: split_panel(prm[i], False, prec) for i in (2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26)}
-        wp[0] = split_panel(w_in56, False, prec)
+        cache = renderer.__dict__.setdefault("_panel_cache", PanelCache())
+        wp = {i: cache.get(i, params[i], prm[i], False, prec) for i in (2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26)}
+        wp[0] = cache.get(0, params[0], w_in56, False, prec)
         for sb in range(SB):
             in56, zl, taps = f(R, 56), f(R, HID), f(R, 8)
             check(L.diner_train_point_inputs(C.byref(scene), _p(lat_nhwc), 1, _p(rays), _p(z), NR, K, sb, _p(in56), _p(zl), _p(taps), st),
@@ -187,11 +210,17 @@ class _RenderFn(torch.autograd.Function):
         ctx.saved_acts, ctx.prm, ctx.w_in56, ctx.lat_shape = saved, prm, w_in56, tuple(latent.shape)
         ctx.keep = (lat,)
         ctx.prec = prec
+        ctx.params = params
         return rgb, depth, weights
 
     @staticmethod
     def backward(ctx, d_rgb, d_depth, d_weights):
         L = _lib.lib()
+        for ref, ver in ctx.versions:
+            t = ref()
+            if t is None or t._version != ver:
+                raise RuntimeError("diner_amd.training: one of the variables needed for gradient computation (an MLP parameter or "
+                                   "encoder.latent) has been modified by an inplace operation between forward and backward")
         scene, rays, z, rgbsigma, prm = ctx.scene, ctx.rays, ctx.z, ctx.rgbsigma, ctx.prm
         dev = rays.device
         st = _st(dev)
@@ -211,7 +240,8 @@ class _RenderFn(torch.autograd.Function):
         g_in56 = torch.zeros_like(ctx.w_in56)
         SBl, NVl, Cl, hl, wl = ctx.lat_shape
         d_lat_nhwc = torch.zeros((SBl, NVl, hl, wl, Cl), dtype=torch.float32, device=dev)
-        wt = {i: split_panel(prm[i], True, prec) for i in (2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28)}
+        cache = ctx.renderer.__dict__.setdefault("_panel_cache", PanelCache())
+        wt = {i: cache.get(i, ctx.params[i], prm[i], True, prec) for i in (2, 4, 6, 8, 10, 12, 14, 16, 18, 20, 22, 24, 26, 28)}
         for sb in range(SB):
             in56, zl, taps, xs, nets, xbars, pnets, xbar5, out = ctx.saved_acts[sb]
             d_out = f(P, 4)

@@ -6,7 +6,7 @@ path on the CPU (``oracle/ref_harness.py``).  Runs only in the build container, 
 
 Each fixture stores: the case configuration (json), the rays, every stage output of the
 reference, and sha256 digests of the seeded inputs (scene maps, latent, MLP weights, noise)
-so a drift of the generators in ``diner_amd/synth.py`` is detected instead of silently
+so a drift of the generators in ``synthetic/synth.py`` is detected instead of silently
 comparing against different inputs.  Inputs themselves are rebuilt from the seeds.
 """
 from __future__ import annotations
@@ -22,7 +22,7 @@ import numpy as np
 ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 
-from diner_amd import synth  # noqa: E402
+from synthetic import synth  # noqa: E402
 
 CASES = {
     # name: scene kwargs, renderer config, ray selection
@@ -107,6 +107,104 @@ def gen_glue(out_dir):
     print(f"glue: rays {rays.shape} normals {normals.shape} nan={np.isnan(normals).sum()}")
 
 
+# ---- upstream wire format + camera-sweep poses -----------------------------------------------------
+WIRE = dict(dtu=dict(seed=31, H=512, W=640, scale_factor=0.7 / 872.0), facescape=dict(seed=32, H=96, W=64))
+
+
+def wire_inputs():
+    """uint16 planes as TransMVSNet writes them (rebuilt from seeds by the tests): smooth surfaces with holes (zeros)."""
+    out = {}
+    c = WIRE["dtu"]
+    rs = np.random.RandomState(c["seed"])
+    yy, xx = np.meshgrid(np.arange(c["H"]), np.arange(c["W"]), indexing="ij")
+    dep = (6000 + 2500 * np.sin(xx / 37.0) * np.cos(yy / 53.0) + rs.randint(0, 40, xx.shape)).astype(np.uint16)
+    dep[rs.rand(*dep.shape) < 0.2] = 0
+    conf = rs.randint(0, 10001, xx.shape).astype(np.uint16)      # confidence in [0,1] x 1e4
+    out["dtu"] = dict(depth=dep, conf=conf)
+    c = WIRE["facescape"]
+    rs = np.random.RandomState(c["seed"])
+    H, W = c["H"], c["W"]
+    gt = rs.randint(0, 30000, (H, W)).astype(np.uint16)
+    pred = rs.randint(8000, 26000, (H, W)).astype(np.uint16)
+    cf = rs.randint(0, 10001, (H, W)).astype(np.uint16)
+    mesh = rs.randint(8000, 26000, (H, W)).astype(np.uint16)
+    for a in (pred, cf, mesh):
+        a[rs.rand(H, W) < 0.35] = 0
+    out["facescape"] = dict(gt=gt, pred=pred, conf=cf, mesh=mesh)
+    return out
+
+
+def pose_inputs():
+    """49 DTU-like camera extrinsics on a dome looking at the origin (world->cam, OpenCV) and 2-4 Facescape source cameras."""
+    rs = np.random.RandomState(41)
+    ext = []
+    for i in range(49):
+        yaw, pitch = -0.9 + 1.8 * (i % 7) / 6.0, -0.5 + 0.7 * (i // 7) / 6.0
+        e = synth.look_at_origin_w2c(yaw, 1.3 + 0.05 * rs.rand()).astype(np.float64)
+        cp, sp = np.cos(pitch), np.sin(pitch)
+        rx = np.array([[1, 0, 0, 0], [0, cp, -sp, 0], [0, sp, cp, 0], [0, 0, 0, 1.0]])
+        ext.append((e @ rx).astype(np.float32))
+    src = np.stack([synth.look_at_origin_w2c(y, 1.75) for y in (-0.45, 0.1, 0.5)]).astype(np.float32)
+    # facescape's sweep assumes z-up world (y_ax = (0,0,-1)): rotate the rig so that its up axis is z
+    to_zup = np.array([[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, 0], [0, 0, 0, 1.0]], np.float32)
+    src = np.stack([e @ to_zup for e in src])
+    return dict(dtu_extrinsics=np.stack(ext), facescape_src_extrinsics=src)
+
+
+def gen_wire(out_dir):
+    """Outputs of the reference's own depth readers / conf2std / get_cam_sweep_extrinsics on PNGs written here with PIL.
+    Full-size outputs are stored as sha256 digests + a strided sample (the DTU reader insists on 512 x 640)."""
+    import tempfile
+    from types import SimpleNamespace as NS
+    import torch
+    from PIL import Image
+    from oracle import ref_harness as rh
+    rh.install_stubs()
+    from src.data.dtu import DTUDataSet
+    from src.data.facescape import FacescapeDataSet
+    w = wire_inputs()
+    fx = {}
+
+    def put(name, arr):
+        arr = np.ascontiguousarray(arr)
+        fx[name + "/sha256"] = digest(arr)
+        fx[name + "/shape"] = np.array(arr.shape)
+        fx[name + "/sample"] = arr.reshape(-1)[::97].copy()
+
+    with tempfile.TemporaryDirectory() as td:
+        # ---- DTU: read_depth on the prediction PNG and on the confidence PNG (dtu.py:100-119, 218-223), conf2std :68-70
+        for ds in (1.0, 0.5):
+            ns = NS(downsample=ds, scale_factor=WIRE["dtu"]["scale_factor"])
+            for key in ("depth", "conf"):
+                Image.fromarray(w["dtu"][key]).save(f"{td}/{key}.png")
+            d, m = DTUDataSet.read_depth(ns, f"{td}/depth.png")
+            c, _ = DTUDataSet.read_depth(ns, f"{td}/conf.png")
+            std = DTUDataSet._getconf2std(ns)(c)
+            put(f"dtu/ds{ds}/depth", d.numpy()), put(f"dtu/ds{ds}/mask", m.numpy()), put(f"dtu/ds{ds}/std", std.numpy())
+        # ---- Facescape: one PNG of three panels gt | pred | conf + the mesh depth PNG (facescape.py:80-104), conf2std :54-56
+        f = w["facescape"]
+        Image.fromarray(np.concatenate([f["gt"], f["pred"], f["conf"]], axis=1)).save(f"{td}/d3.png")
+        Image.fromarray(f["mesh"]).save(f"{td}/mesh.png")
+        conf2std = FacescapeDataSet._getconf2std(NS())
+        for dt in ("original", "mesh", "merge"):
+            p_, c_ = FacescapeDataSet.read_depth(f"{td}/d3.png", f"{td}/mesh.png", depth_type=dt)
+            put(f"facescape/{dt}/depth", p_.numpy()), put(f"facescape/{dt}/std", conf2std(c_).numpy())
+    # ---- camera sweeps (dtu.py:246-340, facescape.py:365-423)
+    pi = pose_inputs()
+    ns = NS(cam_dict=dict(extrinsics=torch.from_numpy(pi["dtu_extrinsics"])))
+    for nf in (5, 12):
+        fx[f"poses/dtu/{nf}"] = DTUDataSet.get_cam_sweep_extrinsics(ns, nf).numpy()
+    src = torch.from_numpy(pi["facescape_src_extrinsics"])
+    ns = NS(range_hor=45, __getitem__=None)
+    ns.__getitem__ = lambda idx: dict(target_extrinsics=src[0], src_extrinsics=src)
+    for nf, kw in ((7, {}), (4, dict(radius=1.5, sweep_range=30))):
+        fx[f"poses/facescape/{nf}"] = FacescapeDataSet.get_cam_sweep_extrinsics(ns, nf, 0, **kw).numpy()
+    fx["digests"] = json.dumps(dict(inputs=digest(*[w["dtu"][k] for k in ("depth", "conf")], *[w["facescape"][k] for k in ("gt", "pred", "conf", "mesh")],
+                                                  pi["dtu_extrinsics"], pi["facescape_src_extrinsics"])))
+    np.savez_compressed(out_dir / "wire.npz", **fx)
+    print(f"wire: {len(fx)} entries, dtu depth sample {fx['dtu/ds1.0/depth/sample'][:3]}, facescape sweep {fx['poses/facescape/7'].shape}")
+
+
 TRAIN_CASE = dict(scene=dict(H=16, W=16, NV=2, seed=12, dataset="facescape", feature_padding=4), K=8, NC=64, G=3,
                   ray_stride=8, focal_scale=1.0, wseed=13, bias_scale=0.1, nseed=14, cseed=15)
 
@@ -170,7 +268,11 @@ def main():
     from oracle import ref_harness as rh
     out_dir = ROOT / "tests" / "golden"
     out_dir.mkdir(parents=True, exist_ok=True)
+    if "--wire-only" in sys.argv:
+        gen_wire(out_dir)
+        return
     if not any(a.startswith("--case=") for a in sys.argv):
+        gen_wire(out_dir)
         gen_glue(out_dir)
         if "--glue-only" in sys.argv:
             return

@@ -66,6 +66,20 @@ class _FakeTrunk(torch.nn.Module):
         self.fc = self.avgpool = torch.nn.Identity()
 
 
+def _pil_to_tensor(pic):
+    a = np.array(pic, copy=True)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    if a.dtype == np.uint16:
+        a = a.astype(np.int32)
+    return torch.from_numpy(a).permute(2, 0, 1).contiguous()
+
+
+def _resize_nearest(x, size, interpolation=None):
+    assert interpolation in (None, "nearest")
+    return torch.nn.functional.interpolate(x, size=list(size), mode="nearest")
+
+
 def install_stubs():
     if "dotmap" not in sys.modules:
         m = types.ModuleType("dotmap")
@@ -80,10 +94,18 @@ def install_stubs():
         mo = types.ModuleType("torchvision.models")
         tr.Normalize = _Normalize
         tr.functional = trf
-        trf.resize = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
+        # dataset readers (src/data/dtu.py, facescape.py; used only by the wire-format / pose goldens): pil_to_tensor is a pure
+        # dtype/layout conversion (PIL image -> integer tensor [C,H,W], values unchanged; a 16-bit PNG is widened to int32 since
+        # torch has no arithmetic on uint16), resize(NEAREST) on a tensor is what torchvision itself calls
+        # (torch.nn.functional.interpolate(mode="nearest")), save_image is unused on the path
+        trf.resize = _resize_nearest
+        trf.pil_to_tensor = _pil_to_tensor
+        tr.InterpolationMode = NS(NEAREST="nearest")
+        tu = types.ModuleType("torchvision.utils")
+        tu.save_image = lambda *a, **k: (_ for _ in ()).throw(NotImplementedError())
         mo.resnet34 = _FakeTrunk
-        tv.transforms, tv.models = tr, mo
-        sys.modules.update({"torchvision": tv, "torchvision.transforms": tr,
+        tv.transforms, tv.models, tv.utils = tr, mo, tu
+        sys.modules.update({"torchvision": tv, "torchvision.transforms": tr, "torchvision.utils": tu,
                             "torchvision.transforms.functional": trf, "torchvision.models": mo})
     sys.dont_write_bytecode = True
     if REFERENCE_ROOT not in sys.path:
@@ -104,7 +126,7 @@ def import_reference():
 # ----------------------------------------------------------------------------------------
 def build_model(scene, weights, image_padding=None, dtype=torch.float32):
     """Reference ``PixelNeRF`` with the scene's maps/cameras and the given MLP weights.
-    ``scene`` is a ``diner_amd.synth.Scene``; ``weights`` a dict from ``make_mlp_weights``."""
+    ``scene`` is a ``synthetic.synth.Scene``; ``weights`` a dict from ``make_mlp_weights``."""
     ref = import_reference()
     image_padding = 2 * scene.feature_padding if image_padding is None else image_padding
     nerf = ref.PixelNeRF(

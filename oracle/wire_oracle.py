@@ -1,7 +1,8 @@
 """TEST INFRASTRUCTURE (never imported by the product path): numpy float32 restatement of the reference's depth /
-confidence readers for the TransMVSNet uint16 planes.  PARITY UNPINNED: the reference ships no fixture for these
-functions and ``torchvision.transforms.functional.pil_to_tensor`` is absent in this image, so the restatement
-follows the source text only (one float32 rounding per tensor operation, python scalars applied as float32).
+confidence readers for the TransMVSNet uint16 planes (one float32 rounding per tensor operation, python scalars applied as
+float32).  Pinned bit-exactly by ``tests/golden/wire.npz``: outputs of the reference's own ``read_depth`` / ``conf2std`` on
+uint16 PNGs written with PIL (``oracle/gen_golden.py --wire-only``; ``pil_to_tensor`` stubbed as a pure dtype/layout
+conversion, ``oracle/ref_harness.py``) -- tests/test_wire.py.
 
 * ``dtu_read_depth``        src/data/dtu.py:100-119   (PNG branch; NEAREST resize for downsample = 1/k)
 * ``dtu_conf2std``          src/data/dtu.py:68-70,220-223
@@ -26,13 +27,16 @@ def dtu_conf2std(x):
     return F(-2.5679e-2) * x + F(3.2818e-2)     # :68-70
 
 
-def facescape_read_depth(depth_u16, conf_u16, mesh_u16=None):
+def facescape_read_depth(depth_u16, conf_u16, mesh_u16=None, depth_type=None):
+    """depth_type: 'original' (default without a mesh plane), 'merge' (default with one) or 'mesh'"""
     pred_mvs = depth_u16.astype(F) * F(1e-4)    # :90
     conf_mvs = conf_u16.astype(F) * F(1e-4)     # :91
     if mesh_u16 is None:                        # depth_type == 'original' :93-94
         return pred_mvs, conf_mvs
     pred = mesh_u16.astype(F) * F(1e-4)         # :82
     conf = np.where(pred == 0, F(0.0), F(0.8))  # :83-85
+    if depth_type == "mesh":                    # :95-96
+        return pred, conf
     pred = np.where((pred == 0) & (pred_mvs != 0), pred_mvs, pred)   # :98-100
     conf = np.where((conf == 0) & (conf_mvs != 0), conf_mvs, conf)   # :101-103
     return pred, conf

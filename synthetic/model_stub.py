@@ -70,7 +70,7 @@ class PixelNeRFState(nn.Module):
 
 
 def model_from_scene(scene, weights, device="cuda", latent: torch.Tensor | None = None) -> PixelNeRFState:
-    """Build the stand-in from a ``diner_amd.synth.Scene`` and a ``make_mlp_weights`` dict.
+    """Build the stand-in from a ``synthetic.synth.Scene`` and a ``make_mlp_weights`` dict.
     ``latent`` may be passed as a device tensor [SB,NV,C,h,w] for scenes generated on the GPU."""
     m = PixelNeRFState(feature_padding=scene.feature_padding)
     sd = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}

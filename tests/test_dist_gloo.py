@@ -11,7 +11,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from diner_amd import synth
+from synthetic import synth
 from diner_amd.dist import all_gather_tiles, render_frame_sharded, shard_bounds
 
 

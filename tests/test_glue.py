@@ -1,12 +1,12 @@
 """The adjacent per-image producers: gen_rays and depth2normal.
-CPU: the numpy restatements in diner_amd/synth.py against goldens from the unmodified reference.
+CPU: the numpy restatements in synthetic/synth.py against goldens from the unmodified reference.
 GPU: the HIP kernels (C ABI) against the same goldens."""
 import json
 
 import numpy as np
 import pytest
 
-from diner_amd import synth
+from synthetic import synth
 from oracle.gen_golden import digest, glue_inputs
 from tests.conftest import GOLDEN_DIR
 
@@ -79,8 +79,9 @@ def test_render_image_equals_chunked_forward():
     """``render_image`` (rays generated on the GPU, one launch) against the reference's flow of
     predict_imgs_from_batch (src/models/diner.py:75-97): gen_rays -> forward on the ray tensor -> view/permute."""
     import torch
-    from diner_amd import NeRFRendererDGS, glue, synth
-    from diner_amd.model_stub import model_from_scene
+    from diner_amd import NeRFRendererDGS, glue
+    from synthetic import synth
+    from synthetic.model_stub import model_from_scene
     dev = torch.device("cuda:0")
     sc = synth.make_scene(24, 32, 3, seed=5, feature_padding=4)
     m = model_from_scene(sc, synth.make_mlp_weights(6, bias_scale=0.1), device=dev)

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from diner_amd import synth
+from synthetic import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -32,7 +32,7 @@ def make(H=24, W=24, NV=3, seed=0, **kw):
 
 def run_gpu(sc, w, rays, K, NC, G, noise, dev, precision="f16x3", want_weights=True):
     from diner_amd import NeRFRendererDGS
-    from diner_amd.model_stub import model_from_scene
+    from synthetic.model_stub import model_from_scene
     m = model_from_scene(sc, w, device=dev)
     r = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G, white_bkgd=sc.white_bkgd)
     r.precision = precision
@@ -147,7 +147,7 @@ def test_rays_that_miss_every_surface(dev):
     K, NC, G = 16, 100, 4
     noise = synth.make_noise(rays.shape[1], NC, G, K, seed=7)
     from diner_amd import NeRFRendererDGS
-    from diner_amd.model_stub import model_from_scene
+    from synthetic.model_stub import model_from_scene
     from oracle.oracle import Oracle
     m = model_from_scene(sc, w, device=dev)
     r = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G)

@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 import torch
 
-from diner_amd import synth
+from synthetic import synth
 from diner_amd.dist import shard_bounds
 
 pytestmark = pytest.mark.gpu
@@ -34,7 +34,7 @@ def T(a, dev):
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_full_size_frame(name):
     from diner_amd import NeRFRendererDGS
-    from diner_amd.model_stub import model_from_scene
+    from synthetic.model_stub import model_from_scene
     from oracle.oracle import Oracle
     c = CASES[name]
     dev = torch.device("cuda:0")

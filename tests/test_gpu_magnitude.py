@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 import torch
 
-from diner_amd import synth
+from synthetic import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -36,7 +36,7 @@ def _case(ls, ws, bs):
 @pytest.mark.parametrize("ls", LATENT)
 def test_f16x3_envelope(ls, ws, bs):
     from diner_amd import NeRFRendererDGS
-    from diner_amd.model_stub import model_from_scene
+    from synthetic.model_stub import model_from_scene
     from oracle.oracle import Oracle
     dev = torch.device("cuda:0")
     sc, w, rays = _case(ls, ws, bs)
@@ -96,7 +96,7 @@ def test_f16x3_envelope(ls, ws, bs):
 def test_nonfinite_is_raised_not_returned():
     """A latent far outside the fp16 range: f16x3 must raise through every entry (deferred, sync and render_image)."""
     from diner_amd import NeRFRendererDGS
-    from diner_amd.model_stub import model_from_scene
+    from synthetic.model_stub import model_from_scene
     dev = torch.device("cuda:0")
     sc, w, rays = _case(1e7, 1.0, 0.0)
     m = model_from_scene(sc, w, device=dev)

@@ -26,7 +26,7 @@ _models = {}
 
 
 def model_for(g, dev):
-    from diner_amd.model_stub import model_from_scene
+    from synthetic.model_stub import model_from_scene
     if g.name not in _models:
         _models[g.name] = model_from_scene(g.scene, g.weights, device=dev)
     return _models[g.name]

@@ -1,12 +1,57 @@
 """Upstream wire format: uint16 depth / confidence planes -> depths, depths_std.
-CPU: the numpy restatement against hand-computed values (parity unpinned: the reference has no fixture for its
-readers).  GPU: the HIP decoder bit-exact against the restatement, feeding the packed maps of the renderer."""
+Pinned by tests/golden/wire.npz = outputs of the reference's own ``DTUDataSet.read_depth`` / ``FacescapeDataSet.read_depth`` /
+``conf2std`` on uint16 PNGs (oracle/gen_golden.py --wire-only): full arrays as sha256 digests + a strided sample.
+CPU: the numpy restatement bit-exact against that fixture (and hand-computed values).  GPU: the HIP decoder bit-exact against
+the fixture and the restatement, feeding the packed maps of the renderer."""
+import hashlib
+
 import numpy as np
 import pytest
 
 from oracle import wire_oracle as wo
+from oracle.gen_golden import WIRE, wire_inputs
+from tests.conftest import GOLDEN_DIR
 
 F = np.float32
+G = dict(np.load(GOLDEN_DIR / "wire.npz", allow_pickle=False))
+
+
+def same_as_fixture(name, arr):
+    """bit-exact: shape, sha256 of the bytes, and the stored strided sample"""
+    arr = np.ascontiguousarray(arr, dtype=np.float32)
+    assert tuple(G[name + "/shape"]) == arr.shape, (name, arr.shape)
+    np.testing.assert_array_equal(arr.reshape(-1)[::97], G[name + "/sample"], err_msg=name)
+    assert hashlib.sha256(arr.tobytes()).hexdigest() == str(G[name + "/sha256"]), name
+
+
+def test_restatement_matches_the_reference_readers():
+    w = wire_inputs()
+    sf = WIRE["dtu"]["scale_factor"]
+    for ds, stride in ((1.0, 1), (0.5, 2)):
+        d, m = wo.dtu_read_depth(w["dtu"]["depth"][None], sf, stride)
+        c, _ = wo.dtu_read_depth(w["dtu"]["conf"][None], sf, stride)
+        same_as_fixture(f"dtu/ds{ds}/depth", d), same_as_fixture(f"dtu/ds{ds}/mask", m), same_as_fixture(f"dtu/ds{ds}/std", wo.dtu_conf2std(c))
+    f = w["facescape"]
+    for dt in ("original", "mesh", "merge"):
+        p, c = wo.facescape_read_depth(f["pred"][None], f["conf"][None], None if dt == "original" else f["mesh"][None], depth_type=dt)
+        same_as_fixture(f"facescape/{dt}/depth", p), same_as_fixture(f"facescape/{dt}/std", wo.facescape_conf2std(c))
+
+
+@pytest.mark.gpu
+def test_hip_decoder_matches_the_reference_readers():
+    from diner_amd import wire
+    w = wire_inputs()
+    sf = WIRE["dtu"]["scale_factor"]
+    for ds in (1.0, 0.5):
+        d, s, m = wire.decode_dtu(w["dtu"]["depth"][None], w["dtu"]["conf"][None], sf, downsample=ds, want_mask=True)
+        same_as_fixture(f"dtu/ds{ds}/depth", d.cpu().numpy()[0]), same_as_fixture(f"dtu/ds{ds}/mask", m.cpu().numpy()[0])
+        same_as_fixture(f"dtu/ds{ds}/std", s.cpu().numpy()[0])
+    f = w["facescape"]
+    zero = np.zeros_like(f["pred"])
+    for dt, (dep, con, mesh) in dict(original=(f["pred"], f["conf"], None), merge=(f["pred"], f["conf"], f["mesh"]),
+                                     mesh=(zero, zero, f["mesh"])).items():   # 'mesh' = merge with empty MVS planes
+        d, s = wire.decode_facescape(dep[None], con[None], None if mesh is None else mesh[None])
+        same_as_fixture(f"facescape/{dt}/depth", d.cpu().numpy()[0]), same_as_fixture(f"facescape/{dt}/std", s.cpu().numpy()[0])
 
 
 def test_restatement_known_answers():
@@ -75,7 +120,8 @@ def test_hip_decoder_facescape_bit_exact(merge):
 def test_decoded_planes_feed_the_map_packing():
     """wire planes -> depths/std -> packed maps (depth2normal fused): the encode-side chain entirely on the GPU."""
     import torch
-    from diner_amd import glue, synth, wire
+    from diner_amd import glue, wire
+    from synthetic import synth
     sc = synth.make_scene(32, 32, 2, seed=3, feature_padding=4)
     dep = np.clip(np.round(sc.depths[0, :, 0] / 1e-4), 0, 65535).astype(np.uint16)        # encode the synthetic depth as a PNG would
     std = np.clip(np.round((sc.depths_std[0, :, 0] - 1.649e-2) / -1.582e-2 / 1e-4), 0, 65535).astype(np.uint16)

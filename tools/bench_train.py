@@ -11,8 +11,9 @@ from pathlib import Path
 import torch
 
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-from diner_amd import NeRFRendererDGS, synth  # noqa: E402
-from diner_amd.model_stub import model_from_scene  # noqa: E402
+from diner_amd import NeRFRendererDGS  # noqa: E402
+from synthetic import synth  # noqa: E402
+from synthetic.model_stub import model_from_scene  # noqa: E402
 
 
 def main(NV=4, H=256, W=256, NR=4096, K=40, G=15, NC=1000, steps=3):

@@ -8,8 +8,9 @@ sys.path.insert(0, ".")
 from pathlib import Path
 from diner_amd import _lib
 if os.environ.get("DINER_LIB_PATH"): _lib.LIB_PATH = Path(os.environ["DINER_LIB_PATH"]).resolve()
-from diner_amd import NeRFRendererDGS, synth
-from diner_amd.model_stub import model_from_scene
+from diner_amd import NeRFRendererDGS
+from synthetic import synth
+from synthetic.model_stub import model_from_scene
 dev = torch.device("cuda:0")
 H = W = 512; NV, K, G, NC = 4, 128, 48, 1000
 sc = synth.make_scene(H, W, NV, seed=0, with_latent=False)

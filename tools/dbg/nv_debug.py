@@ -4,8 +4,9 @@ from diner_amd import _lib
 if os.environ.get("DINER_LIB") == "v1":
     from pathlib import Path
     _lib.LIB_PATH = Path("tools/dbg/libdiner_hip_v1.so").resolve()
-from diner_amd import synth, NeRFRendererDGS
-from diner_amd.model_stub import model_from_scene
+from diner_amd import NeRFRendererDGS
+from synthetic import synth
+from synthetic.model_stub import model_from_scene
 dev = torch.device("cuda:0")
 T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
 print("library:", _lib.LIB_PATH.name)

@@ -4,8 +4,9 @@ import sys
 from pathlib import Path
 import torch
 sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
-from diner_amd import NeRFRendererDGS, synth
-from diner_amd.model_stub import model_from_scene
+from diner_amd import NeRFRendererDGS
+from synthetic import synth
+from synthetic.model_stub import model_from_scene
 
 dev = torch.device("cuda:0")
 sc = synth.make_scene(512, 512, 4, seed=0, dataset="facescape", with_latent=False)
