@@ -39,6 +39,8 @@ import sys
 
 CAP = 96                                        # set by main(): 256 - 128 - 16 * RING
 PRIO = 0                                        # --prio=N: s_setprio N for the S phases, 0 inside the layer blocks
+SPIN_LIMIT = 1 << 18                            # polls before a flow-mode wait gives up (~25 ms; a real wait lasts microseconds)
+FLOW = False                                    # --flow: arrival counters in LDS instead of the three workgroup barriers per layer
 X_OFF, NET_OFF, RING_OFF = 0, 64, 128           # relative to CAP
 
 
@@ -93,6 +95,43 @@ class Block:
                 for tp in range(2):
                     self.e(f"v_mfma_f32_32x32x16_f16 {acc(b, tn, tp)}, {ring(slot, tn, wpart)}, {frags[tp]}, {acc(b, tn, tp)}")
 
+    # ---- synchronisation -------------------------------------------------------------------------------------------------
+    # barrier mode: s_barrier.  flow mode: four monotonic counters in LDS at %[ctr] (byte offsets 0 SA, 4 SB, 8 G1, 12 G2):
+    #   SA / SB  waves 0-3 / 4-7 that have finished their S phase (operand rows written): +4 per layer each
+    #   G1 / G2  waves that have finished reading region 0 / region 1 of the layer: +8 per layer each
+    # %[lay] = number of the layer being executed (1, 2, ...: every wave counts the same sequence); %[half] = 0 / 1.
+    def signal(self, off_expr):
+        """one lane adds 1 to the counter at %[ctr] + off (off_expr: an immediate or 'half' for 4 * %[half])"""
+        self.e("s_waitcnt lgkmcnt(0)")
+        self.e("s_mov_b64 %[ex], exec")
+        self.e("s_mov_b64 exec, 1")
+        if off_expr == "half":
+            self.e("ds_add_u32 %[ctrh], %[one]")
+        elif off_expr == "half+8":
+            self.e("ds_add_u32 %[ctrh], %[one] offset:8")
+        else:
+            self.e(f"ds_add_u32 %[ctr], %[one] offset:{off_expr}")
+        self.e("s_mov_b64 exec, %[ex]")
+
+    def wait(self, addr, off, mult):
+        """spin (with s_sleep) until counter >= mult * %[lay]"""
+        lbl, done = f"W{self.nlabel}_%=", f"D{self.nlabel}_%="
+        self.nlabel += 1
+        self.e(f"s_mul_i32 %[tgt], %[lay], {mult}")
+        self.e(f"s_mov_b32 %[spin], {SPIN_LIMIT}")                   # bounded: a protocol error must end as a wrong result, never as a hung GPU
+        self.e(f"{lbl}:")
+        self.e(f"ds_read_b32 %[pv], %[{addr}] offset:{off}")
+        self.e("s_waitcnt lgkmcnt(0)")
+        self.e("v_readfirstlane_b32 %[cnt], %[pv]")
+        self.e("s_cmp_ge_u32 %[cnt], %[tgt]")
+        self.e(f"s_cbranch_scc1 {done}")
+        self.e("s_sub_u32 %[spin], %[spin], 1")
+        self.e("s_cmp_eq_u32 %[spin], 0")
+        self.e(f"s_cbranch_scc1 {done}")
+        self.e("s_sleep 1")
+        self.e(f"s_branch {lbl}")
+        self.e(f"{done}:")
+
     def body(self, tail, switch):
         """D consecutive k-blocks: k-block j of the iteration consumes ring slot j and fragment buffer j & 1 (D is even).
         tail = the half's last iteration (its last k-block prefetches no fragments); switch = the layer's last
@@ -135,15 +174,33 @@ class Block:
         self.e(f"v_add_u32 %[voff], {(D - 1) * 2048}, %[loff]")      # k-blocks 0..D-2 of this layer are already in the ring
         if PRIO:
             self.e("s_setprio 0")                                     # GEMM at low priority: the partner's S phase (VALU, LDS, gather) goes first
-        self.e("s_waitcnt lgkmcnt(0)")                                # this wave's operand stores (its S phase) have landed
-        self.e("s_barrier")
+        if FLOW:
+            self.signal("half")                                       # my operand rows are written: SA or SB += 1
+            self.wait("ctr", 0, 4)                                    # G1 reads region 0: all of waves 0-3 have written theirs (SA >= 4 lay)
+        else:
+            self.e("s_waitcnt lgkmcnt(0)")                            # this wave's operand stores (its S phase) have landed
+            self.e("s_barrier")
         self.half(self.nkb1, 0, last_half=(self.nkb2 == 0))
-        self.e("s_barrier")
+        if FLOW:
+            self.signal(8)                                            # G1 += 1: my reads of region 0 are over
+            if self.nkb2:
+                self.wait("ctr", 4, 4)                                # G2 reads region 1: SB >= 4 lay
+        else:
+            self.e("s_barrier")
         if self.nkb2:
             self.half(self.nkb2, 1, last_half=True)
         self.e("s_nop 15")                                            # MFMA results -> VALU reads in the glue (XDL write -> VALU read wait states)
         self.e("s_nop 7")
-        self.e("s_barrier")
+        if FLOW:
+            self.signal(12)                                           # G2 += 1 (a layer without a second half signals right away: the counts stay in step)
+            # before this wave may overwrite its operand rows (its next S phase): everybody has finished reading them.  Waves 0-3 own
+            # region 0 (readers: G1), waves 4-7 region 1 (readers: G2).  lin_in keeps BOTH its halves in physical region 0 (unit-rows 0-7),
+            # so behind it waves 0-3 wait for G2 as well; waves 4-7 always see G1 complete once G2 is (each wave runs G1 before G2).
+            self.wait("ctrh", 8, 8)
+            if self.region1_off != 65536:
+                self.wait("ctr", 12, 8)
+        else:
+            self.e("s_barrier")
         if PRIO:
             self.e(f"s_setprio {PRIO}")                               # the glue code that follows (this wave's S phase) outranks the partner's MFMAs
         return self.lines
@@ -163,14 +220,15 @@ def cxx(block):
     return f"""
 // {block.name}: accumulators v[{CAP + block.base}:{CAP + block.base + 63}], {block.nkb1} + {block.nkb2} k-blocks, ring depth {block.D}
 // w0/w1: this wave's weight streams (feature tile 0/1) of THIS layer; nw0/nw1: of the layer executed next
-__device__ __forceinline__ void {block.name}(uint64_t w0, uint64_t w1, uint64_t nw0, uint64_t nw1, unsigned loff, unsigned ab0)
+__device__ __forceinline__ void {block.name}(uint64_t w0, uint64_t w1, uint64_t nw0, uint64_t nw1, unsigned loff, unsigned ab0, const Sync &sy)
 {{
     h8 f00, f01, f02, f03, f10, f11, f12, f13;
     unsigned ab, voff, cnt;
+{flow_decl()}
     asm volatile(
 {asm_body(lines)}
-        : {frag_ops}, [ab] "=&v"(ab), [voff] "=&v"(voff), [cnt] "=&s"(cnt), [w0] "+s"(w0), [w1] "+s"(w1)
-        : [nw0] "s"(nw0), [nw1] "s"(nw1), [loff] "v"(loff), [ab0] "v"(ab0)
+        : {frag_ops}, [ab] "=&v"(ab), [voff] "=&v"(voff), [cnt] "=&s"(cnt), [w0] "+s"(w0), [w1] "+s"(w1){flow_outs()}
+        : [nw0] "s"(nw0), [nw1] "s"(nw1), [loff] "v"(loff), [ab0] "v"(ab0){flow_ins()}
         : "memory", "scc", {clobbers(block.D)});
 }}
 """
@@ -294,6 +352,43 @@ template <> __device__ __forceinline__ void gather_finish<true>(uint64_t G, cons
 """
 
 
+def flow_decl():
+    return "    unsigned pv, tgt, spin; unsigned long long ex;" if FLOW else ""
+
+
+def flow_outs():
+    return ', [pv] "=&v"(pv), [tgt] "=&s"(tgt), [spin] "=&s"(spin), [ex] "=&s"(ex)' if FLOW else ""
+
+
+def flow_ins():
+    return ', [ctr] "v"(sy.ctr), [ctrh] "v"(sy.ctrh), [one] "v"(sy.one), [lay] "s"(sy.lay)' if FLOW else ""
+
+
+def sync_struct():
+    return f"""
+// synchronisation state a layer block takes: barrier mode needs none of it; flow mode ({'ON' if FLOW else 'off'} in this build):
+// ctr = LDS address of the four arrival counters (SA, SB, G1, G2), ctrh = ctr + 4 * (wave >= 4), one = 1, lay = number of the layer
+constexpr bool F16_FLOW = {'true' if FLOW else 'false'};
+struct Sync {{ unsigned ctr, ctrh, one, lay; }};
+// one lane adds 1 to the LDS counter at `addr` (after this wave's LDS operations have completed)
+__device__ __forceinline__ void flow_signal(unsigned addr, unsigned one)
+{{
+    unsigned long long ex;
+    asm volatile(
+{asm_body(["s_waitcnt lgkmcnt(0)", "s_mov_b64 %[ex], exec", "s_mov_b64 exec, 1", "ds_add_u32 %[a], %[one]", "s_mov_b64 exec, %[ex]"])}
+        : [ex] "=&s"(ex) : [a] "v"(addr), [one] "v"(one) : "memory");
+}}
+// spin (with s_sleep) until the LDS counter at `addr` has reached `target`
+__device__ __forceinline__ void flow_wait(unsigned addr, unsigned target)
+{{
+    unsigned pv, cnt, spin;
+    asm volatile(
+{asm_body([f"s_mov_b32 %[spin], {SPIN_LIMIT}", "W_%=:", "ds_read_b32 %[pv], %[a]", "s_waitcnt lgkmcnt(0)", "v_readfirstlane_b32 %[cnt], %[pv]", "s_cmp_ge_u32 %[cnt], %[tgt]", "s_cbranch_scc1 D_%=", "s_sub_u32 %[spin], %[spin], 1", "s_cmp_eq_u32 %[spin], 0", "s_cbranch_scc1 D_%=", "s_sleep 1", "s_branch W_%=", "D_%=:"])}
+        : [pv] "=&v"(pv), [cnt] "=&s"(cnt), [spin] "=&s"(spin) : [a] "v"(addr), [tgt] "s"(target) : "memory", "scc");
+}}
+"""
+
+
 def prologue(D):
     """Fill the ring with k-blocks 0..D-2 of the first layer (once per kernel; afterwards every layer block
     prefetches its successor's first k-blocks)."""
@@ -323,6 +418,8 @@ def main():
     global CAP, PRIO
     CAP = 256 - 128 - 16 * D
     PRIO = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--prio=')), 0)
+    global FLOW
+    FLOW = '--flow' in sys.argv
     out = [f"""// GENERATED by gen_f16_core.py (ring depth {D}{", no weight loads: ablation" if Block.noload else ""}) -- do not edit; see the generator for the design.
 {"namespace " + ns + " {" if ns else "#pragma once"}
 // generator arguments: {" ".join(sys.argv[1:])}
@@ -330,6 +427,7 @@ constexpr int F16_RING = {D};
 constexpr int F16_VGPR_CAP = {CAP};   // hipcc's share (amdgpu_num_vgpr); the core owns v[{CAP}:255]
 constexpr int F16_X = {CAP + X_OFF}, F16_NET = {CAP + NET_OFF};   // first register of the two accumulator grids
 """]
+    out.append(sync_struct())
     out.append(prologue(D))
     out.append(cxx(Block("layer_x_full", X_OFF, 16, 16, D)))
     out.append(cxx(Block("layer_net_full", NET_OFF, 16, 16, D)))

@@ -1,9 +1,9 @@
 import os, sys, numpy as np, torch
 sys.path.insert(0, '.')
 from diner_amd import _lib
-if os.environ.get("DINER_LIB") == "v1":
+if os.environ.get("DINER_LIB") == "v1" or os.environ.get("DINER_LIB_PATH"):
     from pathlib import Path
-    _lib.LIB_PATH = Path("tools/dbg/libdiner_hip_v1.so").resolve()
+    _lib.LIB_PATH = Path(os.environ.get("DINER_LIB_PATH", "tools/dbg/libdiner_hip_v1.so")).resolve()
 from tests.conftest import load_golden
 from tests.test_gpu_parity import renderer_for, model_for, T
 dev = torch.device("cuda:0")
