@@ -432,7 +432,8 @@ constexpr int F16_X = {CAP + X_OFF}, F16_NET = {CAP + NET_OFF};   // first regis
     out.append(cxx(Block("layer_x_full", X_OFF, 16, 16, D)))
     out.append(cxx(Block("layer_net_full", NET_OFF, 16, 16, D)))
     # lin_in: 64 inputs = 4 k-blocks; waves 0-3 write unit-rows 0-3 (k < 32), waves 4-7 unit-rows 4-7 (8 KiB further)
-    out.append(cxx(Block("layer_x_in", X_OFF, 2, 2, D, region1_off=8192)))
+    if D == 2:   # (the ring-4 build is a probe-only variant: tools/chain_probe.hip)
+        out.append(cxx(Block("layer_x_in", X_OFF, 2, 2, D, region1_off=8192)))
     out.append(gather_cxx(D))
     if ns:
         out.append("}  // namespace " + ns + "\n")

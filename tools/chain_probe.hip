@@ -26,16 +26,16 @@ constexpr int IMG_BYTES = 128 * 1024;
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
-// ---- AGPR access from C++ glue ---------------------------------------------------------------------------------
+// ---- the core's registers (high VGPRs reserved from hipcc by amdgpu_num_vgpr) accessed from C++ glue ---------------------------------------------------------------------------------
 template <int N> __device__ __forceinline__ float agpr_read()
 {
     float v;
-    asm volatile("v_accvgpr_read_b32 %0, a%c1" : "=v"(v) : "n"(N));
+    asm volatile("v_mov_b32 %0, v%c1" : "=v"(v) : "n"(N));
     return v;
 }
 template <int N> __device__ __forceinline__ void agpr_write(float v)
 {
-    asm volatile("v_accvgpr_write_b32 a%c0, %1" ::"n"(N), "v"(v));
+    asm volatile("v_mov_b32 v%c0, %1" ::"n"(N), "v"(v));
 }
 
 __device__ __forceinline__ void split(float s, _Float16 &hi, _Float16 &lo)
@@ -108,7 +108,7 @@ __device__ __forceinline__ void init_image_new(char *img, int tid)
 
 #define DEFINE_CHAIN(NS)                                                                                                          \
     template <bool STAGGER, bool STORE>                                                                                           \
-    __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(NS::F16_VGPR_CAP))) void chain_##NS(                         \
+    __global__ __launch_bounds__(512) __attribute__((amdgpu_num_vgpr(NS::F16_VGPR_CAP / 2))) void chain_##NS(                         \
         const _Float16 *__restrict__ W, int NLW, int NL, int tiles, float *__restrict__ out, unsigned long long *__restrict__ clk) \
     {                                                                                                                             \
         __shared__ __attribute__((aligned(16))) char img[IMG_BYTES];                                                              \
@@ -127,21 +127,21 @@ __device__ __forceinline__ void init_image_new(char *img, int tid)
         int layer = 0;                                                                                                            \
         for (int t = 0; t < tiles; ++t) {                                                                                         \
             for (int l = 0; l < NL; l += 2) {                                                                                     \
-                zero_agpr<64>();                                                                                                  \
-                NS::layer_net_full(wptr(layer, 0), wptr(layer, 1), wptr(layer + 1, 0), wptr(layer + 1, 1), loff, ab0);            \
+                zero_agpr<NS::F16_NET>();                                                                                                  \
+                NS::layer_net_full(wptr(layer, 0), wptr(layer, 1), wptr(layer + 1, 0), wptr(layer + 1, 1), loff, ab0, NS::Sync{});            \
                 ++layer;                                                                                                          \
-                if (STORE) store_relu_agpr<64>(img, wave, c, h);                                                                  \
-                zero_agpr<0>();                                                                                                   \
-                NS::layer_x_full(wptr(layer, 0), wptr(layer, 1), wptr(layer + 1, 0), wptr(layer + 1, 1), loff, ab0);              \
+                if (STORE) store_relu_agpr<NS::F16_NET>(img, wave, c, h);                                                                  \
+                zero_agpr<NS::F16_X>();                                                                                                   \
+                NS::layer_x_full(wptr(layer, 0), wptr(layer, 1), wptr(layer + 1, 0), wptr(layer + 1, 1), loff, ab0, NS::Sync{});              \
                 ++layer;                                                                                                          \
-                if (STORE) store_relu_agpr<0>(img, wave, c, h);                                                                   \
+                if (STORE) store_relu_agpr<NS::F16_X>(img, wave, c, h);                                                                   \
             }                                                                                                                     \
         }                                                                                                                         \
         if (STAGGER && wave < 4) __builtin_amdgcn_s_barrier();                                                                    \
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* drain the ring before the wave ends */                                \
         const unsigned long long t1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();                        \
         if (tid == 0) { clk[blockIdx.x * 2] = t1 - t0; clk[blockIdx.x * 2 + 1] = r1 - r0; }                                       \
-        dump_agpr<0>(out + ((int64_t)blockIdx.x * 8 + wave) * 64 * 64 + lane);                                                    \
+        dump_agpr<NS::F16_X>(out + ((int64_t)blockIdx.x * 8 + wave) * 64 * 64 + lane);                                                    \
     }
 DEFINE_CHAIN(d4)
 DEFINE_CHAIN(d2)
@@ -266,6 +266,8 @@ __global__ __launch_bounds__(512) void chain_ref(const _Float16 *__restrict__ W,
 }
 }  // namespace ref
 
+
+
 int main(int argc, char **argv)
 {
     const int tiles = argc > 1 ? atoi(argv[1]) : 32, NL = 28, NLW = 14, reps = argc > 2 ? atoi(argv[2]) : 3;
@@ -296,7 +298,7 @@ int main(int argc, char **argv)
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     unsigned long long *dclk;
     CK(hipMalloc(&dclk, cus * 16));
-    const char *names[] = {"ref", "d4", "d4+stg", "d2", "d2+stg", "d4 nostore", "d4+stg nostore", "d4 noload", "d4+stg noload", "d4 noload nostore"};
+    const char *names[] = {"ref 32x32x16", "d4", "d4+stg", "d2", "d2+stg", "d4 nostore", "d4+stg nostore", "d4 noload", "d4+stg noload", "d4 noload nostore"};
     auto run = [&](int which, float *dst) {
         float best = 1e30f;
         double clock = 0;
