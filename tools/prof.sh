@@ -4,7 +4,7 @@
 # Counters are collected in separate passes and never combined with a trace domain (profiles/README.md).
 set -e
 CFG=${1:-cfg3}; shift || true
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$CFG; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/prof_$CFG; rm -rf $O; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 B="python3 $R/bench.py --config $CFG --no-cpu-baseline $*"
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- $B --steps 2 --warmup 1 > $O/kt.log 2>&1; echo "kernel-trace done"
