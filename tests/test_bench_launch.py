@@ -51,3 +51,23 @@ def test_single_process_stub():
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads(p.stdout.strip())
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["stub_frame_ok"] is True
+
+
+def test_traffic_figure_is_tied_to_the_kernel_sources(monkeypatch):
+    """roofline.traffic is a recorded PMC figure: quoted only while the kernel sources hash to what was profiled."""
+    import argparse
+    import importlib
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    a = argparse.Namespace(config="cfg3", precision="f16x3", rays_per_call=0)
+    val, src = bench.traffic_record(a)
+    rec = json.loads((ROOT / "profiles" / "traffic.json").read_text())["cfg3:f16x3:0"]
+    if rec["kernel_src_sha16"] == bench.kernel_source_digest():
+        assert val == rec["bytes_per_launch"] and "pmc_cfg3" in src
+    else:
+        assert val is None and src.startswith("stale")
+    monkeypatch.setattr(bench, "kernel_source_digest", lambda: "0" * 16)
+    val, src = bench.traffic_record(a)
+    assert val is None and src.startswith("stale")
+    val, src = bench.traffic_record(argparse.Namespace(config="tiny", precision="f16x3", rays_per_call=0))
+    assert val is None
