@@ -36,6 +36,10 @@ class DinerMlpRaw(C.Structure):
                 ("lin_out_w", _FP), ("lin_out_b", _FP)]
 
 
+class DinerTargetCam(C.Structure):
+    _fields_ = [("extrinsics", _FP), ("intrinsics", _FP), ("z_near", _FP), ("z_far", _FP), ("H", C.c_int32), ("W", C.c_int32)]
+
+
 class DinerSamplerCfg(C.Structure):
     _fields_ = [("n_candidates", C.c_int32), ("n_samples", C.c_int32), ("n_gaussian", C.c_int32),
                 ("depth_diff_max", C.c_float)]
@@ -77,6 +81,9 @@ SYMBOLS = {
     "diner_train_head": (C.c_int, [_P, _P, _P, _I64, _P, _I32, _P]),
     "diner_composite_backward": (C.c_int, [_P, _P, _P, _P, _P, _P, _I64, _I32, _I32, _P, _P]),
     "diner_render_workspace_floats": (_I64, [_I64, _I64, _I32, _I32, _I32]),
+    "diner_render_image_workspace_floats": (_I64, [_I64, _I32, _I32, _I32, _I32, _I32]),
+    "diner_render_image": (C.c_int, [C.POINTER(DinerScene), _P, C.POINTER(DinerTargetCam), C.POINTER(DinerSamplerCfg), _I32, _I32, _U64,
+                                     _P, _P, _P, _P, _P, _P, _P]),
     "diner_render": (C.c_int, [C.POINTER(DinerScene), _P, _P, _I64, C.POINTER(DinerSamplerCfg), _I32, _I32,
                                _P, _P, _P, _U64, _P, _P, _P, _P, _P, _P]),
 }

@@ -55,8 +55,8 @@ int launch_pack_maps_from_depth(const float *, const float *, const float *, int
 int launch_decode_depth(const unsigned short *, const unsigned short *, const unsigned short *, int64_t, int, int, int, float, float, float,
                         float, float, float *, float *, float *, hipStream_t);
 int launch_linz_maps(const float *, int64_t, const float *, float *, hipStream_t);
-int launch_sampler(const DinerScene &, const float *, int64_t, const DinerSamplerCfg &, const float *, const float *,
-                   const float *, const float *, uint64_t, float *, float *, float *, hipStream_t);
+int launch_sampler(const DinerScene &, const float *, const DinerTargetCam *, float *, int64_t, const DinerSamplerCfg &, const float *,
+                   const float *, const float *, const float *, uint64_t, float *, float *, float *, hipStream_t);
 int launch_sample_coarse(const float *, int64_t, int, const float *, uint64_t, float *, hipStream_t);
 int launch_fill_up(const float *, const float *, int64_t, int, const float *, uint64_t, float *, hipStream_t);
 int launch_points_mlp(const DinerScene &, const float *, const float *, const float *, int64_t, int, float *, hipStream_t);
@@ -198,7 +198,7 @@ int diner_sample_depthguided(const DinerScene *scene, const float *rays, int64_t
     if ((rc = check_scene(scene, false)) || (rc = check_cfg(cfg))) return rc;
     if (NR < 0) return bad("NR < 0");
     if (NR > 0 && scene->SB > 0 && (!rays || !z_out)) return bad("sample_depthguided: NULL rays / z_out");
-    return launch_sampler(*scene, rays, NR, *cfg, u_coarse, n_gauss, u_fill, z_cand, seed, z_out, z_dg_out, lik_out,
+    return launch_sampler(*scene, rays, nullptr, nullptr, NR, *cfg, u_coarse, n_gauss, u_fill, z_cand, seed, z_out, z_dg_out, lik_out,
                           (hipStream_t)stream);
 }
 
@@ -345,6 +345,32 @@ int diner_render(const DinerScene *scene, const float *mlp_packed, const float *
     float *z = workspace, *rgbsigma = workspace + N * cfg->n_samples, *scratch = workspace + N * cfg->n_samples * 5;
     if ((rc = diner_sample_depthguided(scene, rays, NR, cfg, u_coarse, n_gauss, u_fill, nullptr, seed, z, nullptr,
                                        nullptr, stream)))
+        return rc;
+    if ((rc = diner_render_points(scene, mlp_packed, rays, z, NR, cfg->n_samples, precision, scratch, rgbsigma, stream))) return rc;
+    return diner_composite(rays, z, rgbsigma, N, cfg->n_samples, white_bkgd, rgb_out, depth_out, weights_out, status, stream);
+}
+
+int64_t diner_render_image_workspace_floats(int64_t SB, int32_t H, int32_t W, int32_t K, int32_t NV, int32_t precision)
+{
+    const int64_t NR = (int64_t)H * W;
+    return SB * NR * 8 + diner_render_workspace_floats(SB, NR, K, NV, precision);
+}
+
+int diner_render_image(const DinerScene *scene, const float *mlp_packed, const DinerTargetCam *cam, const DinerSamplerCfg *cfg,
+                       int32_t white_bkgd, int32_t precision, uint64_t seed, float *workspace, float *rays_out, float *rgb_out,
+                       float *depth_out, float *weights_out, uint32_t *status, void *stream)
+{
+    int rc;
+    if ((rc = check_scene(scene, true)) || (rc = check_cfg(cfg))) return rc;
+    if (!cam || !cam->extrinsics || !cam->intrinsics || !cam->z_near || !cam->z_far) return bad("render_image: NULL camera");
+    if (cam->H <= 0 || cam->W <= 0) return bad("render_image: bad image size");
+    if (scene->SB == 0) return DINER_OK;
+    if (!workspace) return bad("render_image: workspace is NULL");
+    const int64_t NR = (int64_t)cam->H * cam->W, N = (int64_t)scene->SB * NR;
+    float *rays = rays_out ? rays_out : workspace;                 // generated by the sampler, read by the two later stages
+    float *z = workspace + N * 8, *rgbsigma = z + N * cfg->n_samples, *scratch = z + N * cfg->n_samples * 5;
+    if ((rc = launch_sampler(*scene, nullptr, cam, rays, NR, *cfg, nullptr, nullptr, nullptr, nullptr, seed, z, nullptr, nullptr,
+                             (hipStream_t)stream)))
         return rc;
     if ((rc = diner_render_points(scene, mlp_packed, rays, z, NR, cfg->n_samples, precision, scratch, rgbsigma, stream))) return rc;
     return diner_composite(rays, z, rgbsigma, N, cfg->n_samples, white_bkgd, rgb_out, depth_out, weights_out, status, stream);

@@ -127,9 +127,11 @@ class Block:
         self.e(f"s_cbranch_scc1 {done}")
         self.e("s_sub_u32 %[spin], %[spin], 1")
         self.e("s_cmp_eq_u32 %[spin], 0")
-        self.e(f"s_cbranch_scc1 {done}")
+        self.e(f"s_cbranch_scc1 T{lbl}")
         self.e("s_sleep 1")
         self.e(f"s_branch {lbl}")
+        self.e(f"T{lbl}:")                                             # timed out: poison this wave's x grid -> every sample of the tile comes out
+        self.e(f"v_mov_b32 v{CAP + X_OFF}, 0x7fc00000")               # NaN -> the compositing kernel raises DINER_STATUS_NONFINITE (loud, no hang)
         self.e(f"{done}:")
 
     def body(self, tail, switch):
@@ -378,13 +380,14 @@ __device__ __forceinline__ void flow_signal(unsigned addr, unsigned one)
 {asm_body(["s_waitcnt lgkmcnt(0)", "s_mov_b64 %[ex], exec", "s_mov_b64 exec, 1", "ds_add_u32 %[a], %[one]", "s_mov_b64 exec, %[ex]"])}
         : [ex] "=&s"(ex) : [a] "v"(addr), [one] "v"(one) : "memory");
 }}
-// spin (with s_sleep) until the LDS counter at `addr` has reached `target`
-__device__ __forceinline__ void flow_wait(unsigned addr, unsigned target)
+// spin (with s_sleep) until the LDS counter at `addr` has reached `target`; false if the bounded spin gave up
+__device__ __forceinline__ bool flow_wait(unsigned addr, unsigned target)
 {{
     unsigned pv, cnt, spin;
     asm volatile(
 {asm_body([f"s_mov_b32 %[spin], {SPIN_LIMIT}", "W_%=:", "ds_read_b32 %[pv], %[a]", "s_waitcnt lgkmcnt(0)", "v_readfirstlane_b32 %[cnt], %[pv]", "s_cmp_ge_u32 %[cnt], %[tgt]", "s_cbranch_scc1 D_%=", "s_sub_u32 %[spin], %[spin], 1", "s_cmp_eq_u32 %[spin], 0", "s_cbranch_scc1 D_%=", "s_sleep 1", "s_branch W_%=", "D_%=:"])}
         : [pv] "=&v"(pv), [cnt] "=&s"(cnt), [spin] "=&s"(spin) : [a] "v"(addr), [tgt] "s"(target) : "memory", "scc");
+    return spin != 0;
 }}
 """
 

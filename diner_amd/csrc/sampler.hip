@@ -142,7 +142,7 @@ __device__ __forceinline__ float candidate_u_philox(int j, int64_t gray, uint2 k
 
 template <int CPL>  // candidates per lane: NC <= 64*CPL
 __global__ __launch_bounds__(64) void sampler_kernel(
-    DinerScene s, const float *__restrict__ rays, int64_t NR, DinerSamplerCfg cfg,
+    DinerScene s, const float *__restrict__ rays, DinerTargetCam cam, float *__restrict__ rays_gen, int64_t NR, DinerSamplerCfg cfg,
     const float *__restrict__ u_coarse, const float *__restrict__ n_gauss, const float *__restrict__ u_fill,
     const float *__restrict__ z_cand, uint64_t seed, float *__restrict__ z_out, float *__restrict__ z_dg_out,
     float *__restrict__ lik_out)
@@ -152,8 +152,28 @@ __global__ __launch_bounds__(64) void sampler_kernel(
     const int sb = blockIdx.y;
     const int64_t ray = blockIdx.x, gray = (int64_t)sb * NR + ray;
     const int NC = cfg.n_candidates, K = cfg.n_samples, G = cfg.n_gaussian, keep = K - G;
-    const float *rp = rays + gray * 8;
-    const float ox = rp[0], oy = rp[1], oz = rp[2], dx = rp[3], dy = rp[4], dz = rp[5], near = rp[6], far = rp[7];
+    float ox, oy, oz, dx, dy, dz, near, far;
+    if (cam.extrinsics) {
+        // gen_rays fused (src/util/cam_geometry.py:36-79, same arithmetic as encode_glue.hip's gen_rays_kernel): ray `ray` of scene
+        // sb is pixel (ray / W, ray % W) of the target camera; stored once for the point kernel and the compositing
+        const float *E = cam.extrinsics + sb * 16, *Kk = cam.intrinsics + sb * 9;
+        const int py = (int)(ray / cam.W), px = (int)(ray - (int64_t)py * cam.W);
+        float cx_ = (((float)px + 0.5f) - Kk[2]) / Kk[0], cy_ = (((float)py + 0.5f) - Kk[5]) / Kk[4], cz_ = 1.0f;   // :62-63
+        const float n = sqrtf(cx_ * cx_ + cy_ * cy_ + cz_ * cz_);                                                   // :64
+        cx_ = cx_ / n; cy_ = cy_ / n; cz_ = cz_ / n;
+        float o3[3], d3[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {   // world direction = R^T d, origin = -R^T t (:67-72)
+            d3[r] = __builtin_fmaf(E[2 * 4 + r], cz_, __builtin_fmaf(E[1 * 4 + r], cy_, E[0 * 4 + r] * cx_));
+            o3[r] = __builtin_fmaf(-1.0f * E[2 * 4 + r], E[2 * 4 + 3], __builtin_fmaf(-1.0f * E[1 * 4 + r], E[1 * 4 + 3], (-1.0f * E[0 * 4 + r]) * E[0 * 4 + 3]));
+        }
+        ox = o3[0]; oy = o3[1]; oz = o3[2]; dx = d3[0]; dy = d3[1]; dz = d3[2];
+        near = cam.z_near[sb]; far = cam.z_far[sb];
+        if (lane < 8) rays_gen[gray * 8 + lane] = lane == 0 ? ox : lane == 1 ? oy : lane == 2 ? oz : lane == 3 ? dx : lane == 4 ? dy : lane == 5 ? dz : lane == 6 ? near : far;
+    } else {
+        const float *rp = rays + gray * 8;
+        ox = rp[0]; oy = rp[1]; oz = rp[2]; dx = rp[3]; dy = rp[4]; dz = rp[5]; near = rp[6]; far = rp[7];
+    }
     const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
 
     // ---- candidates (sample_coarse, :53-60) ---------------------------------------------------
@@ -347,15 +367,17 @@ int launch_fill_up(const float *rays, const float *z_in, int64_t N, int K, const
     return check_launch("fill_up_kernel");
 }
 
-int launch_sampler(const DinerScene &s, const float *rays, int64_t NR, const DinerSamplerCfg &cfg,
+int launch_sampler(const DinerScene &s, const float *rays, const DinerTargetCam *cam, float *rays_gen, int64_t NR, const DinerSamplerCfg &cfg,
                    const float *u_coarse, const float *n_gauss, const float *u_fill, const float *z_cand,
                    uint64_t seed, float *z_out, float *z_dg_out, float *lik_out, hipStream_t st)
 {
     if (NR == 0 || s.SB == 0) return DINER_OK;
     const size_t lds = sort_lds_bytes(cfg.n_samples);
     const dim3 grid((unsigned)NR, (unsigned)s.SB), block(64);
+    DinerTargetCam tc = {nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (cam) tc = *cam;
 #define DINER_LAUNCH_SAMPLER(CPL)                                                                              \
-    hipLaunchKernelGGL(sampler_kernel<CPL>, grid, block, lds, st, s, rays, NR, cfg, u_coarse, n_gauss, u_fill, \
+    hipLaunchKernelGGL(sampler_kernel<CPL>, grid, block, lds, st, s, rays, tc, rays_gen, NR, cfg, u_coarse, n_gauss, u_fill, \
                        z_cand, seed, z_out, z_dg_out, lik_out)
     const int NC = cfg.n_candidates;
     if (NC <= 64 * 4) DINER_LAUNCH_SAMPLER(4);

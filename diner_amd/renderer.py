@@ -458,23 +458,37 @@ class NeRFRendererDGS(torch.nn.Module):
     @torch.no_grad()
     def render_image(self, model, target_extrinsics, target_intrinsics, H, W, z_near, z_far, return_depth=False):
         """The render half of ``DINER.predict_imgs_from_batch`` (reference src/models/diner.py:75-97) without the
-        ray-batch loop: rays of the whole target image(s) are generated on the GPU (``diner_gen_rays``,
-        src/util/cam_geometry.py:36-79) and rendered in ONE launch per stage (the native mode: no 4096-ray chunks,
-        no ``torch.cat``), output in the reference's image layout.
+        ray-batch loop and without a rays tensor round trip: ``gen_rays`` (src/util/cam_geometry.py:36-79) is evaluated
+        inside the sampler kernel (``diner_render_image``), the whole target image is ONE launch per stage (no 4096-ray
+        chunks, no ``torch.cat``), output in the reference's image layout.  Bit-identical to ``forward(gen_rays(...))``.
         :param target_extrinsics: [SB,4,4] world->cam;  target_intrinsics: [SB,3,3];  z_near, z_far: [SB] or scalars
         :return: rgb [SB,3,H,W] (, depth [SB,1,H,W])"""
-        from . import glue
-        SB = target_extrinsics.shape[0]
+        self._validate_model(model)
         dev = target_extrinsics.device
-        zn = torch.as_tensor(z_near, dtype=torch.float32, device=dev).expand(SB)
-        zf = torch.as_tensor(z_far, dtype=torch.float32, device=dev).expand(SB)
-        rays = glue.gen_rays(target_extrinsics, target_intrinsics, W, H, zn, zf).view(SB, H * W, 8)
-        out = self.forward(model, rays).fine
-        if self.finite_check != "off":
-            self.check_finite()                      # once per frame: a NaN image never leaves this function
-        rgb = out.rgb.view(SB, H, W, 3).permute(0, 3, 1, 2)
+        SB = target_extrinsics.shape[0]
+        E, Ki = _f32c(target_extrinsics), _f32c(target_intrinsics)
+        zn = torch.as_tensor(z_near, dtype=torch.float32, device=dev).expand(SB).contiguous()
+        zf = torch.as_tensor(z_far, dtype=torch.float32, device=dev).expand(SB).contiguous()
+        packed = self._mlp(model)
+        sc, _keep = self._scene(model, need_latent=True, packed_mlp=packed)
+        assert SB == sc.SB
+        K = int(self.n_samples)
+        cfg = self._cfg(K, self.n_depth_candidates, self.n_gaussian)
+        cam = _lib.DinerTargetCam()
+        cam.extrinsics, cam.intrinsics, cam.z_near, cam.z_far = E.data_ptr(), Ki.data_ptr(), zn.data_ptr(), zf.data_ptr()
+        cam.H, cam.W = int(H), int(W)
+        prec = _lib.PRECISIONS[self.precision]
+        L = _lib.lib()
+        ws = torch.empty(int(L.diner_render_image_workspace_floats(SB, int(H), int(W), K, sc.NV, prec)), dtype=torch.float32, device=dev)
+        rgb = torch.empty((SB, H * W, 3), dtype=torch.float32, device=dev)
+        depth = torch.empty((SB, H * W), dtype=torch.float32, device=dev)
+        self._poll_status()
+        check(L.diner_render_image(C.byref(sc), _ptr(packed), C.byref(cam), C.byref(cfg), int(bool(self.white_bkgd)), prec, self._next_seed(),
+                                   _ptr(ws), None, _ptr(rgb), _ptr(depth), None, _ptr(self._status_word(dev)), _stream(dev)), "diner_render_image")
+        self._after_launch(dev, sync=self.finite_check != "off")    # once per frame: a NaN image never leaves this function
+        rgb = rgb.view(SB, H, W, 3).permute(0, 3, 1, 2)
         if return_depth:
-            return rgb, out.depth.view(SB, H, W, 1).permute(0, 3, 1, 2)
+            return rgb, depth.view(SB, H, W, 1).permute(0, 3, 1, 2)
         return rgb
 
     def _forward_train(self, model, rays, want_weights, noise=None, z_samples=None):

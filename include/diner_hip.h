@@ -83,6 +83,16 @@ typedef struct DinerSamplerCfg {
     float depth_diff_max;    /* 0.05 (src/models/nerf_renderer.py:67) */
 } DinerSamplerCfg;
 
+/* Target cameras for diner_render_image: the sampler generates each ray from its pixel instead of reading a rays tensor
+ * (gen_rays fused into the sampler; src/util/cam_geometry.py:36-79). */
+typedef struct DinerTargetCam {
+    const float *extrinsics; /* [SB,4,4] world->camera */
+    const float *intrinsics; /* [SB,3,3] */
+    const float *z_near;     /* [SB] */
+    const float *z_far;      /* [SB] */
+    int32_t H, W;            /* target image size: rays per scene = H*W, ray r = pixel (r / W, r % W) */
+} DinerTargetCam;
+
 const char *diner_last_error(void);
 int diner_version(void);
 
@@ -185,6 +195,17 @@ int diner_render(const DinerScene *scene, const float *mlp_packed, const float *
                  const DinerSamplerCfg *cfg, int32_t white_bkgd, int32_t precision, const float *u_coarse,
                  const float *n_gauss, const float *u_fill, uint64_t seed, float *workspace,
                  float *rgb_out, float *depth_out, float *weights_out, uint32_t *status, void *stream);
+
+/* Replaces the render half of DINER.predict_imgs_from_batch (src/models/diner.py:75-97): gen_rays
+ * (src/util/cam_geometry.py:36-79) is evaluated INSIDE the sampler kernel -- a wave computes its ray from the pixel index and
+ * the target camera, and stores it once for the two later stages -- then the three stages run as in diner_render.
+ * workspace: diner_render_image_workspace_floats(...) floats (rays | z | rgbsigma | scratch).  Outputs [SB,H*W,3], [SB,H*W],
+ * [SB,H*W,K]|NULL; rays_out [SB,H*W,8]|NULL also hands the generated rays to the caller. */
+int64_t diner_render_image_workspace_floats(int64_t SB, int32_t H, int32_t W, int32_t K, int32_t NV, int32_t precision);
+int diner_render_image(const DinerScene *scene, const float *mlp_packed, const DinerTargetCam *cam,
+                       const DinerSamplerCfg *cfg, int32_t white_bkgd, int32_t precision, uint64_t seed,
+                       float *workspace, float *rays_out, float *rgb_out, float *depth_out, float *weights_out,
+                       uint32_t *status, void *stream);
 
 /* ---- training path: building blocks of the forward-with-saved-activations and
  * the backward of composite (src/models/nerf_renderer.py:286-365) + PixelNeRF.forward

@@ -100,3 +100,55 @@ def test_render_image_equals_chunked_forward():
     assert torch.equal(rgb, ref.rgb.view(1, H, W, 3).permute(0, 3, 1, 2))
     assert torch.equal(depth, ref.depth.view(1, H, W, 1).permute(0, 3, 1, 2))
     assert float(rgb.min()) >= -1e-5 and float(rgb.max()) <= 1 + 1e-5
+
+
+@pytest.mark.gpu
+def test_render_image_abi_rays_out_and_two_scenes():
+    """``diner_render_image`` through the C-ABI: the rays the sampler generates (``rays_out``) are bit-identical to
+    ``diner_gen_rays`` (src/util/cam_geometry.py:36-79) for two scenes with different target cameras, and the image equals
+    ``diner_render`` on those rays with the same seed."""
+    import ctypes as C
+    import torch
+    from diner_amd import NeRFRendererDGS, _lib, glue
+    from diner_amd.renderer import _ptr, _stream, check
+    from synthetic import synth
+    from synthetic.model_stub import model_from_scene
+    dev = torch.device("cuda:0")
+    import copy
+    a, b = synth.make_scene(24, 32, 2, seed=9, feature_padding=4), synth.make_scene(24, 32, 2, seed=10, feature_padding=4)
+    sc = copy.copy(a)
+    for name in ("poses", "focal", "c", "depths", "depths_std", "normals", "latent"):
+        setattr(sc, name, np.concatenate([getattr(a, name), getattr(b, name)], 0))
+    m = model_from_scene(sc, synth.make_mlp_weights(2, bias_scale=0.1), device=dev)
+    r = NeRFRendererDGS(n_samples=16, n_depth_candidates=128, n_gaussian=5, white_bkgd=sc.white_bkgd)
+    H, W, K = 12, 20, 16
+    E0 = torch.from_numpy(np.ascontiguousarray(sc.target_extrinsics, dtype=np.float32)).to(dev)
+    E = torch.stack([E0, E0.clone()])
+    E[1, :3, 3] += torch.tensor([0.02, -0.01, 0.03], device=dev)
+    Kt = torch.tensor([[[1.2 * W, 0, W / 2], [0, 1.2 * W, H / 2], [0, 0, 1]], [[1.1 * W, 0, W / 2 + 1], [0, 1.3 * W, H / 2 - 1], [0, 0, 1]]],
+                      dtype=torch.float32, device=dev)
+    zn = torch.tensor([float(sc.near), float(sc.near) * 1.05], device=dev)
+    zf = torch.tensor([float(sc.far), float(sc.far) * 0.95], device=dev)
+    packed = r._mlp(m)
+    scn, _keep = r._scene(m, need_latent=True, packed_mlp=packed)
+    cfg = r._cfg(K, 128, 5)
+    cam = _lib.DinerTargetCam()
+    cam.extrinsics, cam.intrinsics, cam.z_near, cam.z_far, cam.H, cam.W = E.data_ptr(), Kt.data_ptr(), zn.data_ptr(), zf.data_ptr(), H, W
+    L, prec = _lib.lib(), _lib.PRECISIONS[r.precision]
+    ws = torch.empty(int(L.diner_render_image_workspace_floats(2, H, W, K, scn.NV, prec)), dtype=torch.float32, device=dev)
+    rays_out = torch.full((2, H * W, 8), float("nan"), device=dev)
+    rgb, depth = torch.empty((2, H * W, 3), device=dev), torch.empty((2, H * W), device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(L.diner_render_image(C.byref(scn), _ptr(packed), C.byref(cam), C.byref(cfg), int(bool(sc.white_bkgd)), prec, 77, _ptr(ws), _ptr(rays_out),
+                               _ptr(rgb), _ptr(depth), None, _ptr(status), _stream(dev)), "diner_render_image")
+    rays = glue.gen_rays(E, Kt, W, H, zn, zf).view(2, H * W, 8)
+    assert torch.equal(rays_out, rays)
+    ws2 = torch.empty(int(L.diner_render_workspace_floats(2, H * W, K, scn.NV, prec)), dtype=torch.float32, device=dev)
+    rgb2, depth2 = torch.empty_like(rgb), torch.empty_like(depth)
+    check(L.diner_render(C.byref(scn), _ptr(packed), _ptr(rays), H * W, C.byref(cfg), int(bool(sc.white_bkgd)), prec, None, None, None, 77, _ptr(ws2),
+                         _ptr(rgb2), _ptr(depth2), None, _ptr(status), _stream(dev)), "diner_render")
+    assert torch.equal(rgb, rgb2) and torch.equal(depth, depth2) and int(status.cpu()[0]) == 0
+    # NULL camera / bad size are refused, not launched
+    assert L.diner_render_image(C.byref(scn), _ptr(packed), None, C.byref(cfg), 0, prec, 0, _ptr(ws), None, _ptr(rgb), _ptr(depth), None, None, None) != 0
+    cam.H = 0
+    assert L.diner_render_image(C.byref(scn), _ptr(packed), C.byref(cam), C.byref(cfg), 0, prec, 0, _ptr(ws), None, _ptr(rgb), _ptr(depth), None, None, None) != 0
