@@ -40,6 +40,8 @@ import sys
 CAP = 96                                        # set by main(): 256 - 128 - 16 * RING
 PRIO = 0                                        # --prio=N: s_setprio N for the S phases, 0 inside the layer blocks
 SPIN_LIMIT = 1 << 18                            # polls before a flow-mode wait gives up (~25 ms; a real wait lasts microseconds)
+WBITS = ""                                      # --wbits=nt|sc0|...: cache-policy bits of the weight-stream loads
+STAMPS = False                                  # --stamps: diagnostic layer blocks only (namespace of --ns), 6 s_memtime stamps each (tools/trace_f16.py)
 FLOW = False                                    # --flow: arrival counters in LDS instead of the three workgroup barriers per layer
 X_OFF, NET_OFF, RING_OFF = 0, 64, 128           # relative to CAP
 
@@ -72,8 +74,8 @@ class Block:
         for tn, w in ((0, "%[w0]"), (1, "%[w1]")):
             if self.noload:
                 continue
-            self.e(f"global_load_dwordx4 {ring(slot, tn, 0)}, %[voff], {w}")
-            self.e(f"global_load_dwordx4 {ring(slot, tn, 1)}, %[voff], {w} offset:1024")
+            self.e(f"global_load_dwordx4 {ring(slot, tn, 0)}, %[voff], {w}{WBITS}")
+            self.e(f"global_load_dwordx4 {ring(slot, tn, 1)}, %[voff], {w} offset:1024{WBITS}")
         self.e("v_add_u32 %[voff], 2048, %[voff]")
 
     def switch_to_next(self):
@@ -112,6 +114,12 @@ class Block:
         else:
             self.e(f"ds_add_u32 %[ctr], %[one] offset:{off_expr}")
         self.e("s_mov_b64 exec, %[ex]")
+
+    def stamp(self, i):
+        """diagnostic build: clock into st.t[i]; SMEM returns out of order with LDS, so drain before any counted lgkmcnt wait"""
+        if STAMPS:
+            self.e(f"s_memtime %[tk{i}]")
+            self.e("s_waitcnt lgkmcnt(0)")
 
     def wait(self, addr, off, mult):
         """spin (with s_sleep) until counter >= mult * %[lay]"""
@@ -177,16 +185,20 @@ class Block:
         if PRIO:
             self.e("s_setprio 0")                                     # GEMM at low priority: the partner's S phase (VALU, LDS, gather) goes first
         if FLOW:
+            self.stamp(0)
             self.signal("half")                                       # my operand rows are written: SA or SB += 1
             self.wait("ctr", 0, 4)                                    # G1 reads region 0: all of waves 0-3 have written theirs (SA >= 4 lay)
+            self.stamp(1)
         else:
             self.e("s_waitcnt lgkmcnt(0)")                            # this wave's operand stores (its S phase) have landed
             self.e("s_barrier")
         self.half(self.nkb1, 0, last_half=(self.nkb2 == 0))
         if FLOW:
+            self.stamp(2)
             self.signal(8)                                            # G1 += 1: my reads of region 0 are over
             if self.nkb2:
                 self.wait("ctr", 4, 4)                                # G2 reads region 1: SB >= 4 lay
+            self.stamp(3)
         else:
             self.e("s_barrier")
         if self.nkb2:
@@ -194,6 +206,7 @@ class Block:
         self.e("s_nop 15")                                            # MFMA results -> VALU reads in the glue (XDL write -> VALU read wait states)
         self.e("s_nop 7")
         if FLOW:
+            self.stamp(4)
             self.signal(12)                                           # G2 += 1 (a layer without a second half signals right away: the counts stay in step)
             # before this wave may overwrite its operand rows (its next S phase): everybody has finished reading them.  Waves 0-3 own
             # region 0 (readers: G1), waves 4-7 region 1 (readers: G2).  lin_in keeps BOTH its halves in physical region 0 (unit-rows 0-7),
@@ -201,6 +214,7 @@ class Block:
             self.wait("ctrh", 8, 8)
             if self.region1_off != 65536:
                 self.wait("ctr", 12, 8)
+            self.stamp(5)
         else:
             self.e("s_barrier")
         if PRIO:
@@ -222,14 +236,14 @@ def cxx(block):
     return f"""
 // {block.name}: accumulators v[{CAP + block.base}:{CAP + block.base + 63}], {block.nkb1} + {block.nkb2} k-blocks, ring depth {block.D}
 // w0/w1: this wave's weight streams (feature tile 0/1) of THIS layer; nw0/nw1: of the layer executed next
-__device__ __forceinline__ void {block.name}(uint64_t w0, uint64_t w1, uint64_t nw0, uint64_t nw1, unsigned loff, unsigned ab0, const Sync &sy)
+__device__ __forceinline__ void {block.name}(uint64_t w0, uint64_t w1, uint64_t nw0, uint64_t nw1, unsigned loff, unsigned ab0, const Sync &sy{", Stamps &st" if STAMPS else ""})
 {{
     h8 f00, f01, f02, f03, f10, f11, f12, f13;
     unsigned ab, voff, cnt;
 {flow_decl()}
     asm volatile(
 {asm_body(lines)}
-        : {frag_ops}, [ab] "=&v"(ab), [voff] "=&v"(voff), [cnt] "=&s"(cnt), [w0] "+s"(w0), [w1] "+s"(w1){flow_outs()}
+        : {frag_ops}, [ab] "=&v"(ab), [voff] "=&v"(voff), [cnt] "=&s"(cnt), [w0] "+s"(w0), [w1] "+s"(w1){flow_outs()}{"".join(f', [tk{i}] "=&s"(st.t[{i}])' for i in range(6)) if STAMPS else ""}
         : [nw0] "s"(nw0), [nw1] "s"(nw1), [loff] "v"(loff), [ab0] "v"(ab0){flow_ins()}
         : "memory", "scc", {clobbers(block.D)});
 }}
@@ -421,8 +435,21 @@ def main():
     global CAP, PRIO
     CAP = 256 - 128 - 16 * D
     PRIO = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--prio=')), 0)
-    global FLOW
+    global FLOW, STAMPS, WBITS
+    WBITS = next((" " + a.split("=", 1)[1].replace(",", " ") for a in sys.argv[1:] if a.startswith("--wbits=")), "")
     FLOW = '--flow' in sys.argv
+    STAMPS = '--stamps' in sys.argv
+    if STAMPS:
+        assert ns and FLOW and D == 2
+        out = [f"// GENERATED by gen_f16_core.py {' '.join(sys.argv[1:])} -- do not edit.  Diagnostic twins of the layer blocks: the same code plus 6 clock\n"
+               f"// stamps (entry | region 0 ready | G1 done | region 1 ready | G2 done | operand rows free), used by the TRACE kernel only.\n"
+               f"namespace {ns} {{\nstruct Stamps {{ unsigned long long t[6]; }};\n"]
+        out.append(cxx(Block("layer_x_full", X_OFF, 16, 16, D)))
+        out.append(cxx(Block("layer_net_full", NET_OFF, 16, 16, D)))
+        out.append(cxx(Block("layer_x_in", X_OFF, 2, 2, D, region1_off=8192)))
+        out.append("}  // namespace " + ns + "\n")
+        sys.stdout.write("\n".join(out))
+        return
     out = [f"""// GENERATED by gen_f16_core.py (ring depth {D}{", no weight loads: ablation" if Block.noload else ""}) -- do not edit; see the generator for the design.
 {"namespace " + ns + " {" if ns else "#pragma once"}
 // generator arguments: {" ".join(sys.argv[1:])}

@@ -38,6 +38,9 @@ def test_generated_core_is_current():
     args = re.search(r"// generator arguments: (.*)", (CSRC / "f16_core.inc").read_text()).group(1).split()
     out = subprocess.run(["python3", str(CSRC / "gen_f16_core.py"), *args], check=True, capture_output=True, text=True).stdout
     assert out == (CSRC / "f16_core.inc").read_text()
+    # the diagnostic twins (TRACE kernel only): the same blocks with clock stamps
+    out = subprocess.run(["python3", str(CSRC / "gen_f16_core.py"), *args, "--ns=tr", "--stamps"], check=True, capture_output=True, text=True).stdout
+    assert out == (CSRC / "f16_core_trace.inc").read_text()
 
 
 def test_compiler_stays_out_of_the_core_registers(isa):

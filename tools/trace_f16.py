@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Timeline of one tile of the fused point/MLP kernel (diagnostic build, DINER_F16_TRACE=1): runs one cfg3-like launch, parses the
-[f16 trace] lines and prints per wave the duration of every S phase (glue) and of every layer block (between its stamps).
+[f16 trace] lines and prints per wave and layer block the glue time before it and the five phases inside it (waits on the arrival counters, the two GEMM halves).
     DINER_F16_TRACE=1 python tools/trace_f16.py 2> trace.txt ; python tools/trace_f16.py --parse trace.txt"""
 import os, re, sys
 import numpy as np
 
-NAMES = {1: "tile", 10: "S->in", 11: "in|", 20: "S->net", 21: "net|", 30: "S->x", 31: "x|", 40: "S->head", 41: "head bar|", 42: "head red|"}
-
 def parse(path):
+    """per layer block of a wave: S (glue before the block) | waitA (region 0 ready) | G1 | waitB (region 1 ready) | G2 | waitF (operand
+    rows free); events 100..105 are the stamps inside the generated block (f16_core_trace.inc), 10/20/30 name the block that follows."""
     waves = {}
     for l in open(path):
         m = re.match(r"\[f16 trace\] wave(\d+):(.*)", l)
@@ -15,19 +15,25 @@ def parse(path):
             waves[int(m.group(1))] = [(int(a), int(b)) for a, b in (t.split(":") for t in m.group(2).split())]
     if not waves:
         print("no trace lines"); return
-    t0 = min(ev[0][1] for ev in waves.values())
     for w, ev in sorted(waves.items()):
-        s_time = blk_time = 0
-        segs = []
-        for (ida, ta), (idb, tb) in zip(ev[:-1], ev[1:]):
-            d = tb - ta
-            if idb in (10, 20, 30, 40):   # S phase ends at idb
-                s_time += d; segs.append(f"S{d}")
+        print(f"wave{w}: (start {ev[0][1]})")
+        prev_end, i, last_block = ev[0][1], 0, "?"
+        tot = dict(S=0, waitA=0, G1=0, waitB=0, G2=0, waitF=0)
+        while i < len(ev):
+            if ev[i][0] in (10, 20, 30):
+                last_block = {10: "in ", 20: "net", 30: "x  "}[ev[i][0]]
+            if ev[i][0] == 100 and i + 5 < len(ev):
+                t = [ev[i + k][1] for k in range(6)]
+                d = [t[0] - prev_end] + [t[k + 1] - t[k] for k in range(5)]
+                print(f"  {last_block} @{t[0]:>8}  " + "  ".join(f"{k} {v:>6}" for k, v in zip(tot, d)))
+                for k, v in zip(tot, d):
+                    tot[k] += v
+                prev_end = t[5]
+                i += 6
             else:
-                blk_time += d; segs.append(f"[{NAMES.get(idb, idb)}{d}]")
-        tot = ev[-1][1] - ev[0][1]
-        print(f"wave{w}: start {ev[0][1]-t0} total {tot} cycles  S {s_time} ({100*s_time/tot:.1f}%)  blocks {blk_time} ({100*blk_time/tot:.1f}%)")
-        print("   " + " ".join(segs))
+                i += 1
+        T = max(1, sum(tot.values()))
+        print("  totals: " + "  ".join(f"{k} {v} ({100 * v / T:.1f}%)" for k, v in tot.items()))
 
 if "--parse" in sys.argv:
     parse(sys.argv[sys.argv.index("--parse") + 1]); sys.exit(0)
