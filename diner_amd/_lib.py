@@ -72,6 +72,8 @@ SYMBOLS = {
     "diner_train_amax": (C.c_int, [_P, _I64, _P, _P]),
     "diner_train_colsum_amax": (C.c_int, [_P, _I64, _I32, _I64, _P, _P, _P]),
     "diner_train_split_panel": (C.c_int, [_P, _I32, _I64, _I32, _I32, _P, _P, _P]),
+    "diner_train_pack_core": (C.c_int, [_P, _I64, _I32, _I32, _P, _P]),
+    "diner_train_gemm_core": (C.c_int, [_P, _I64, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I64, _I32, _P, _I32, _I32, _P, _P, _P]),
     "diner_train_gemm_panel": (C.c_int, [_P, _I64, _P, _P, _P, _P, _I64, _P, _I64, _P, _I64, _I64, _I32, _I32, _P, _I32, _I32, _P]),
     "diner_train_colsum": (C.c_int, [_P, _I64, _I32, _I64, _P, _P]),
     "diner_train_point_inputs": (C.c_int, [C.POINTER(DinerScene), _P, _I32, _P, _P, _I64, _I32, _I32, _P, _P, _P, _P]),

@@ -38,6 +38,9 @@ int launch_train_gemm(const float *, const float *, const float *, const float *
 int launch_train_amax(const float *, int64_t, unsigned int *, hipStream_t);
 int launch_train_colsum_amax(const float *, int64_t, int, int64_t, float *, unsigned int *, hipStream_t);
 int launch_train_split_panel(const float *, int, int64_t, int, int, void *, void *, hipStream_t);
+int launch_train_pack_core(const float *, int64_t, int, int, void *, hipStream_t);
+int launch_train_gemm_core(const float *, int64_t, const void *, const float *, const float *, int64_t, const float *, int64_t, float *, int64_t,
+                           int64_t, int, const unsigned int *, int, int, float *, unsigned int *, hipStream_t);
 int launch_train_gemm_panel(const float *, int64_t, const void *, const void *, const float *, const float *, int64_t, const float *,
                             int64_t, float *, int64_t, int64_t, int, int, const unsigned int *, int, int, hipStream_t);
 int launch_train_colsum(const float *, int64_t, int, int64_t, float *, hipStream_t);
@@ -274,6 +277,27 @@ int diner_train_gemm_panel(const float *A, int64_t sam, const void *Bhi, const v
     if (exp_a < -60 || exp_a > 60 || exp_b < -60 || exp_b > 60) return bad("train_gemm_panel: scale exponent out of range");
     return launch_train_gemm_panel(A, sam, Bhi, Blo, bias, S, lds, addend, ldadd, C, ldc, M, K, relu_a, (const unsigned int *)amax_a, exp_a,
                                    exp_b, (hipStream_t)stream);
+}
+
+int diner_train_pack_core(const float *W, int64_t ld, int32_t transpose, int32_t exp, void *out, void *stream)
+{
+    if (!W || !out) return bad("train_pack_core: NULL pointer");
+    if (ld < DINER_D_HIDDEN || exp < -60 || exp > 60) return bad("train_pack_core: bad leading dimension / exponent");
+    return launch_train_pack_core(W, ld, transpose, exp, out, (hipStream_t)stream);
+}
+
+int diner_train_gemm_core(const float *A, int64_t sam, const void *Wcore, const float *bias, const float *S, int64_t lds, const float *addend,
+                          int64_t ldadd, float *C, int64_t ldc, int64_t M, int32_t relu_a, const void *amax_a, int32_t exp_a, int32_t exp_b,
+                          float *colsum, void *amax_out, void *stream)
+{
+    if (!A || !Wcore || !C) return bad("train_gemm_core: NULL pointer");
+    if (M < 0 || sam < DINER_D_HIDDEN || (sam & 3) || ldc < DINER_D_HIDDEN || (ldc & 3) || (S && (lds & 3)) || (addend && (ldadd & 3)))
+        return bad("train_gemm_core: bad size (K = N = 512; leading dimensions % 4 must be 0)");
+    if (((uintptr_t)A & 15) || ((uintptr_t)Wcore & 15) || ((uintptr_t)C & 15) || ((uintptr_t)bias & 15) || ((uintptr_t)S & 15) || ((uintptr_t)addend & 15))
+        return bad("train_gemm_core: operands must be 16-byte aligned");
+    if (exp_a < -60 || exp_a > 60 || exp_b < -60 || exp_b > 60) return bad("train_gemm_core: scale exponent out of range");
+    return launch_train_gemm_core(A, sam, Wcore, bias, S, lds, addend, ldadd, C, ldc, M, relu_a, (const unsigned int *)amax_a, exp_a, exp_b, colsum,
+                                  (unsigned int *)amax_out, (hipStream_t)stream);
 }
 
 int diner_train_colsum(const float *dY, int64_t M, int32_t N, int64_t ld, float *db, void *stream)

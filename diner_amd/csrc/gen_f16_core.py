@@ -40,6 +40,7 @@ import sys
 CAP = 96                                        # set by main(): 256 - 128 - 16 * RING
 PRIO = 0                                        # --prio=N: s_setprio N for the S phases, 0 inside the layer blocks
 SPIN_LIMIT = 1 << 18                            # polls before a flow-mode wait gives up (~25 ms; a real wait lasts microseconds)
+PRIO_B = 0                                      # --priob=N: GEMM priority of waves 4-7 (waves 0-3: 0)
 WBITS = ""                                      # --wbits=nt|sc0|...: cache-policy bits of the weight-stream loads
 STAMPS = False                                  # --stamps: diagnostic layer blocks only (namespace of --ns), 6 s_memtime stamps each (tools/trace_f16.py)
 FLOW = False                                    # --flow: arrival counters in LDS instead of the three workgroup barriers per layer
@@ -184,6 +185,12 @@ class Block:
         self.e(f"v_add_u32 %[voff], {(D - 1) * 2048}, %[loff]")      # k-blocks 0..D-2 of this layer are already in the ring
         if PRIO:
             self.e("s_setprio 0")                                     # GEMM at low priority: the partner's S phase (VALU, LDS, gather) goes first
+            if PRIO_B:                                                # ... and waves 4-7 (the critical path: they never wait) ahead of waves 0-3
+                self.e("s_cmp_lg_u32 %[half], 0")
+                self.e(f"s_cbranch_scc0 PB{self.nlabel}_%=")
+                self.e(f"s_setprio {PRIO_B}")
+                self.e(f"PB{self.nlabel}_%=:")
+                self.nlabel += 1
         if FLOW:
             self.stamp(0)
             self.signal("half")                                       # my operand rows are written: SA or SB += 1
@@ -377,15 +384,15 @@ def flow_outs():
 
 
 def flow_ins():
-    return ', [ctr] "v"(sy.ctr), [ctrh] "v"(sy.ctrh), [one] "v"(sy.one), [lay] "s"(sy.lay)' if FLOW else ""
+    return ', [ctr] "v"(sy.ctr), [ctrh] "v"(sy.ctrh), [one] "v"(sy.one), [lay] "s"(sy.lay), [half] "s"(sy.half)' if FLOW else ""
 
 
 def sync_struct():
     return f"""
 // synchronisation state a layer block takes: barrier mode needs none of it; flow mode ({'ON' if FLOW else 'off'} in this build):
-// ctr = LDS address of the four arrival counters (SA, SB, G1, G2), ctrh = ctr + 4 * (wave >= 4), one = 1, lay = number of the layer
+// ctr = LDS address of the four arrival counters (SA, SB, G1, G2), ctrh = ctr + 4 * (wave >= 4), one = 1, lay = number of the layer, half = (wave >= 4)
 constexpr bool F16_FLOW = {'true' if FLOW else 'false'};
-struct Sync {{ unsigned ctr, ctrh, one, lay; }};
+struct Sync {{ unsigned ctr, ctrh, one, lay, half; }};
 // one lane adds 1 to the LDS counter at `addr` (after this wave's LDS operations have completed)
 __device__ __forceinline__ void flow_signal(unsigned addr, unsigned one)
 {{
@@ -435,7 +442,8 @@ def main():
     global CAP, PRIO
     CAP = 256 - 128 - 16 * D
     PRIO = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--prio=')), 0)
-    global FLOW, STAMPS, WBITS
+    global FLOW, STAMPS, WBITS, PRIO_B
+    PRIO_B = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--priob=')), 0)
     WBITS = next((" " + a.split("=", 1)[1].replace(",", " ") for a in sys.argv[1:] if a.startswith("--wbits=")), "")
     FLOW = '--flow' in sys.argv
     STAMPS = '--stamps' in sys.argv

@@ -53,12 +53,28 @@ def amax_of(t, prec):
     return out
 
 
+USE_CORE = True   # 512 x 512 layers: the inference kernel's assembly GEMM core (train_core.hip) instead of the panel kernel
+
+
+class CorePack:
+    """A 512 x 512 weight in the stream layout of the GEMM core (``diner_train_pack_core``)."""
+    __slots__ = ("data",)
+
+    def __init__(self, data):
+        self.data = data
+
+
 def split_panel(W, transpose, prec):
-    """Weight operand of the panel GEMM (f16x3 mode): fp16 hi/lo planes of B[n][k] = W[n][k] (forward) or W[k][n]
-    (transpose: the dX GEMM), 512 rows each; None when the panel kernel does not apply (fp32 mode, not 512 columns)."""
+    """Weight operand of the pre-split-weight GEMMs (f16x3 mode): B[n][k] = W[n][k] (forward) or W[k][n] (transpose: the dX
+    GEMM), 512 rows.  K = 512: a ``CorePack`` (GEMM core of the inference kernel); other K: fp16 hi/lo planes of the panel
+    kernel; None when neither applies (fp32 mode, not 512 columns)."""
     n_rows, K = (W.shape[1], W.shape[0]) if transpose else (W.shape[0], W.shape[1])
     if prec == 0 or n_rows != HID:
         return None
+    if USE_CORE and K == HID and W.stride(1) == 1:
+        data = torch.empty(2 * HID * HID, dtype=torch.float16, device=W.device)
+        check(_lib.lib().diner_train_pack_core(_p(W), W.stride(0), int(transpose), EXP_W, _p(data), _st(W.device)), "diner_train_pack_core")
+        return CorePack(data)
     kpad = (K + 31) // 32 * 32
     planes = torch.empty((2, HID * kpad), dtype=torch.float16, device=W.device)
     check(_lib.lib().diner_train_split_panel(_p(W), K, W.stride(0), int(transpose), EXP_W, _p(planes[0]), _p(planes[1]), _st(W.device)),
@@ -83,8 +99,14 @@ class PanelCache:
         return planes
 
 
-def _panel(A, planes, bias, S, addend, out, relu_a, amax, exp_a):
+def _panel(A, planes, bias, S, addend, out, relu_a, amax, exp_a, colsum=None, amax_out=None):
     M, K = A.shape
+    if isinstance(planes, CorePack):
+        check(_lib.lib().diner_train_gemm_core(_p(A), A.stride(0), _p(planes.data), _p(bias), _p(S), 0 if S is None else S.stride(0),
+                                               _p(addend), 0 if addend is None else addend.stride(0), _p(out), out.stride(0), M, int(relu_a),
+                                               _p(amax), exp_a, EXP_W, _p(colsum), _p(amax_out), _st(out.device)), "diner_train_gemm_core")
+        return
+    assert colsum is None and amax_out is None
     check(_lib.lib().diner_train_gemm_panel(_p(A), A.stride(0), _p(planes[0]), _p(planes[1]), _p(bias), _p(S), 0 if S is None else S.stride(0),
                                             _p(addend), 0 if addend is None else addend.stride(0), _p(out), out.stride(0), M, K, int(relu_a),
                                             _p(amax), exp_a, EXP_W, _st(out.device)), "diner_train_gemm_panel")
@@ -120,6 +142,24 @@ def linear_bwd_x(dY, W, mask_src, out, addend=None, prec=0, amax=None, panel=Non
         out.copy_(addend)
     _gemm(dY, W, None, mask_src, out, M, K, N, dY.stride(0), 1, W.stride(0), 1, out.stride(0),
           0 if mask_src is None else mask_src.stride(0), accumulate=int(addend is not None), prec=prec, amax_a=amax, exp_b=EXP_W)
+
+
+def linear_bwd_x_reduced(dY, W, mask_src, out, dbs, addend=None, prec=0, amax=None, panel=None):
+    """``linear_bwd_x`` followed by ``colsum_amax`` of its result: every ``db`` of ``dbs`` += column sums of ``out``; returns the
+    max|out| word.  On the GEMM core both reductions ride in the GEMM's epilogue (no extra pass over ``out``)."""
+    if not isinstance(panel, CorePack):
+        linear_bwd_x(dY, W, mask_src, out, addend=addend, prec=prec, amax=amax, panel=panel)
+        word = colsum_amax(out, dbs[0], prec)
+        for db in dbs[1:]:
+            check(_lib.lib().diner_train_colsum(_p(out), out.shape[0], out.shape[1], out.stride(0), _p(db), _st(out.device)), "diner_train_colsum")
+        return word
+    word = torch.zeros(1, dtype=torch.int32, device=out.device)
+    cs = dbs[0] if len(dbs) == 1 else torch.zeros(HID, dtype=torch.float32, device=out.device)
+    _panel(dY, panel, None, mask_src, addend, out, False, amax, 0, colsum=cs, amax_out=word)
+    if len(dbs) > 1:
+        for db in dbs:   # db += cs (the colsum kernel on a one-row matrix)
+            check(_lib.lib().diner_train_colsum(_p(cs), 1, HID, HID, _p(db), _st(out.device)), "diner_train_colsum")
+    return word
 
 
 def linear_bwd_w(dY, X, dW, db, relu_x=False, prec=0, amax=None):
@@ -249,33 +289,36 @@ class _RenderFn(torch.autograd.Function):
             a_out = colsum_amax(d_out, g[29], prec)
             linear_bwd_w(d_out, xbar5, g[28], None, relu_x=True, prec=prec, amax=a_out)
             d_x = f(P, HID)
-            linear_bwd_x(d_out, prm[28], xbar5, d_x, prec=prec, amax=a_out, panel=wt[28])
+            a_x = linear_bwd_x_reduced(d_out, prm[28], xbar5, d_x, [g[27]], prec=prec, amax=a_out, panel=wt[28])
             for i, b in ((1, 4), (0, 3)):                                         # post-mean blocks, reversed
-                d_net = f(P, HID)
-                a_x = colsum_amax(d_x, g[11 + 4 * b], prec)
-                linear_bwd_x(d_x, prm[10 + 4 * b], pnets[i], d_net, prec=prec, amax=a_x, panel=wt[10 + 4 * b])
+                d_net = f(P, HID)                                                  # (a_x, g[11 + 4b]: reduced by the GEMM that produced d_x)
+                a_net = linear_bwd_x_reduced(d_x, prm[10 + 4 * b], pnets[i], d_net, [g[9 + 4 * b]], prec=prec, amax=a_x, panel=wt[10 + 4 * b])
                 linear_bwd_w(d_x, pnets[i], g[10 + 4 * b], None, relu_x=True, prec=prec, amax=a_x)
                 d_prev = f(P, HID)
-                a_net = colsum_amax(d_net, g[9 + 4 * b], prec)
-                linear_bwd_x(d_net, prm[8 + 4 * b], xbars[i], d_prev, addend=d_x, prec=prec, amax=a_net, panel=wt[8 + 4 * b])
+                if b == 4:
+                    a_prev = linear_bwd_x_reduced(d_net, prm[8 + 4 * b], xbars[i], d_prev, [g[11 + 4 * (b - 1)]], addend=d_x, prec=prec, amax=a_net,
+                                                  panel=wt[8 + 4 * b])
+                else:
+                    linear_bwd_x(d_net, prm[8 + 4 * b], xbars[i], d_prev, addend=d_x, prec=prec, amax=a_net, panel=wt[8 + 4 * b])
+                    a_prev = None
                 linear_bwd_w(d_net, xbars[i], g[8 + 4 * b], None, relu_x=True, prec=prec, amax=a_net)
-                d_x = d_prev
+                d_x, a_x = d_prev, a_prev
             d_xv = f(R, HID)
             check(L.diner_train_view_mean(_p(d_x), P * HID, NV, _p(d_xv), 1, st), "diner_train_view_mean(bwd)")
+            a_xv = colsum_amax(d_xv, g[11 + 4 * 2], prec)
             d_zl = f(R, HID)          # written by the first (b = 2) lin_z backward, accumulated by the other two
             for b in (2, 1, 0):                                                   # per-view blocks, reversed
                 d_net = f(R, HID)
-                a_xv = colsum_amax(d_xv, g[11 + 4 * b], prec)
-                linear_bwd_x(d_xv, prm[10 + 4 * b], nets[b], d_net, prec=prec, amax=a_xv, panel=wt[10 + 4 * b])
+                a_net = linear_bwd_x_reduced(d_xv, prm[10 + 4 * b], nets[b], d_net, [g[9 + 4 * b]], prec=prec, amax=a_xv, panel=wt[10 + 4 * b])
                 linear_bwd_w(d_xv, nets[b], g[10 + 4 * b], None, relu_x=True, prec=prec, amax=a_xv)
                 d_xs = f(R, HID)
-                a_net = colsum_amax(d_net, g[9 + 4 * b], prec)
-                linear_bwd_x(d_net, prm[8 + 4 * b], xs[b], d_xs, addend=d_xv, prec=prec, amax=a_net, panel=wt[8 + 4 * b])
+                # d_xs is the dY of lin_z[b] AND of the previous block's fc_1 (the residual stream): one reduction, two bias gradients
+                a_xs = linear_bwd_x_reduced(d_net, prm[8 + 4 * b], xs[b], d_xs, [g[3 + 2 * b]] + ([g[11 + 4 * (b - 1)]] if b else []), addend=d_xv,
+                                            prec=prec, amax=a_net, panel=wt[8 + 4 * b])
                 linear_bwd_w(d_net, xs[b], g[8 + 4 * b], None, relu_x=True, prec=prec, amax=a_net)
-                a_xs = colsum_amax(d_xs, g[3 + 2 * b], prec)
                 linear_bwd_w(d_xs, zl, g[2 + 2 * b], None, prec=prec, amax=a_xs)          # lin_z[b]
                 linear_bwd_x(d_xs, prm[2 + 2 * b], None, d_zl, addend=None if b == 2 else d_zl, prec=prec, amax=a_xs, panel=wt[2 + 2 * b])
-                d_xv = d_xs
+                d_xv, a_xv = d_xs, a_xs
             linear_bwd_w(d_xv, in56, g_in56, None, prec=prec, amax=a_xs)           # lin_in (its d_xv is lin_z[0]'s d_xs)
             check(L.diner_train_bilinear_scatter(_p(d_zl), _p(taps), P, HID, scene.h, scene.w, NV, sb, _p(d_lat_nhwc), st),
                   "diner_train_bilinear_scatter")

@@ -245,6 +245,16 @@ int diner_train_gemm_panel(const float *A, int64_t sam, const void *Bhi, const v
                            const float *S, int64_t lds, const float *addend, int64_t ldadd, float *C, int64_t ldc,
                            int64_t M, int32_t K, int32_t relu_a, const void *amax_a, int32_t exp_a, int32_t exp_b,
                            void *stream);
+/* Weight operand of diner_train_gemm_core: B[n][k] = (transpose ? W[k*ld + n] : W[n*ld + k]) * 2^exp, n, k < 512, fp16 hi/lo in the
+ * stream layout of the inference kernel's GEMM core (points_mlp_f16.hip, "packed weight image"): out = 512*512*2 halfs. */
+int diner_train_pack_core(const float *W, int64_t ld, int32_t transpose, int32_t exp, void *out, void *stream);
+/* diner_train_gemm_panel for K = 512 on the inference kernel's assembly GEMM core (same f16x3 arithmetic; A read and split once per
+ * 64-row tile, the weights L2 -> registers, no workgroup barrier in the loop).  Optionally folds the two reductions of
+ * diner_train_colsum_amax over the RESULT into the epilogue: colsum[n] += sum_m C[m][n], *amax_out = max(*amax_out, bits of max|C|)
+ * (either may be NULL).  Reference: the Linear layers of ResnetFC (src/models/resnetfc.py:62-69) and their autograd transposes. */
+int diner_train_gemm_core(const float *A, int64_t sam, const void *Wcore, const float *bias, const float *S, int64_t lds,
+                          const float *addend, int64_t ldadd, float *C, int64_t ldc, int64_t M, int32_t relu_a, const void *amax_a,
+                          int32_t exp_a, int32_t exp_b, float *colsum, void *amax_out, void *stream);
 /* db[n] += sum_m dY[m*ld + n] */
 int diner_train_colsum(const float *dY, int64_t M, int32_t N, int64_t ld, float *db, void *stream);
 /* per (view, point) row = v*P + p of scene sb: in56 [R,56] (55 inputs of pixelnerf.py:128 + 0), z [R,512]

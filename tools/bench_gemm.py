@@ -29,7 +29,13 @@ def main(M=655360, reps=3):
             "dW": lambda: T.linear_bwd_w(dY, X, dw, None, relu_x=True, prec=prec, amax=a),
         }
         if prec:
+            T.USE_CORE = False
             wp, wtp = T.split_panel(W, False, prec), T.split_panel(W, True, prec)
+            T.USE_CORE = True
+            wc, wtc = T.split_panel(W, False, prec), T.split_panel(W, True, prec)
+            cases["fwd core"] = lambda: T.linear_fwd(X, W, b, out, relu_in=True, prec=prec, panel=wc)
+            cases["fwd+add core"] = lambda: T.linear_fwd(X, W, b, out, relu_in=True, addend=out, prec=prec, panel=wc)
+            cases["dX core"] = lambda: T.linear_bwd_x(dY, W, X, out, prec=prec, amax=a, panel=wtc)
             cases["fwd panel"] = lambda: T.linear_fwd(X, W, b, out, relu_in=True, prec=prec, panel=wp)
             cases["fwd+add panel"] = lambda: T.linear_fwd(X, W, b, out, relu_in=True, addend=out, prec=prec, panel=wp)
             cases["dX panel"] = lambda: T.linear_bwd_x(dY, W, X, out, prec=prec, amax=a, panel=wtp)
