@@ -253,19 +253,46 @@ __device__ __forceinline__ unsigned tile_load(f32x4 (&v)[4], const float *__rest
     return ok;
 }
 
+// (x * sc, floored) -> fp16 hi / lo pairs: hi = cvt_pk(t), lo = fma_mix(hi * -1 + t) rounded once to fp16 = (f16)(t - (float)hi) (the
+// difference is exact in fp32).  2.5 VALU slots per value (4.5 with the relu) where the C++ form costs hipcc about 8: scalar converts
+// both ways, v_pack; in the dW kernel that split, not the MFMAs, was the longest phase of a k-step.
+// RELU keeps NaN like torch.relu: v_cmp_ngt + v_cndmask, the 4 compares ahead of the 4 selects (gfx950: 2 wait states between a VALU
+// write of an SGPR and its VALU read).
+template <bool RELU>
+__device__ __forceinline__ void split4_pk(float x0, float x1, float x2, float x3, float sc, unsigned &h01, unsigned &h23, unsigned &l01, unsigned &l23)
+{
+    float t0, t1, t2, t3;
+    if constexpr (RELU) {
+        unsigned long long m0, m1, m2, m3;
+        asm volatile("v_mul_f32 %4, %12, %16\n\tv_mul_f32 %5, %13, %16\n\tv_mul_f32 %6, %14, %16\n\tv_mul_f32 %7, %15, %16\n\t"
+                     "v_cmp_ngt_f32_e64 %8, 0, %4\n\tv_cmp_ngt_f32_e64 %9, 0, %5\n\tv_cmp_ngt_f32_e64 %10, 0, %6\n\tv_cmp_ngt_f32_e64 %11, 0, %7\n\t"
+                     "v_cndmask_b32_e64 %4, 0, %4, %8\n\tv_cndmask_b32_e64 %5, 0, %5, %9\n\tv_cndmask_b32_e64 %6, 0, %6, %10\n\tv_cndmask_b32_e64 %7, 0, %7, %11\n\t"
+                     "v_cvt_pk_f16_f32 %0, %4, %5\n\tv_cvt_pk_f16_f32 %1, %6, %7\n\t"
+                     "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                     : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+                     : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(sc));
+    } else {
+        asm volatile("v_mul_f32 %4, %8, %12\n\tv_mul_f32 %5, %9, %12\n\tv_mul_f32 %6, %10, %12\n\tv_mul_f32 %7, %11, %12\n\t"
+                     "v_cvt_pk_f16_f32 %0, %4, %5\n\tv_cvt_pk_f16_f32 %1, %6, %7\n\t"
+                     "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                     : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                     : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(sc));
+    }
+}
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 __device__ __forceinline__ void put4(h8 *Thi, h8 *Tlo, int l, int kq, float x0, float x1, float x2, float x3, float floor_, float sc)
 {
-    const float x[4] = {x0, x1, x2, x3};
-    h4 hi, lo;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const float ts = x[j] * sc, t = ts < floor_ ? floor_ : ts;  // floor_ = 0 applies the relu, -inf does nothing; NaN stays NaN
-        hi[j] = (_Float16)t;
-        lo[j] = (_Float16)(t - (float)hi[j]);
-    }
+    u32x2 hi, lo;   // floor_ = 0 applies the relu, -inf does nothing (wave-uniform); NaN stays NaN
+    unsigned a, b, c, d;
+    if (floor_ == 0.0f) split4_pk<true>(x0, x1, x2, x3, sc, a, b, c, d);
+    else split4_pk<false>(x0, x1, x2, x3, sc, a, b, c, d);
+    hi.x = a; hi.y = b; lo.x = c; lo.y = d;
     const int o = unit(kq >> 3, l) * 8 + (kq & 4);
-    *(h4 *)((_Float16 *)Thi + o) = hi;
-    *(h4 *)((_Float16 *)Tlo + o) = lo;
+    *(u32x2 *)((_Float16 *)Thi + o) = hi;
+    *(u32x2 *)((_Float16 *)Tlo + o) = lo;
 }
 
 template <bool KC>
@@ -273,9 +300,13 @@ __device__ __forceinline__ void tile_store(h8 *Thi, h8 *Tlo, const f32x4 (&v)[4]
 {
     f32x4 x[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < 4; ++i) x[i] = v[i];
+    if (ok != 0xFu) {   // ragged edge of the operand only
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[i][j] = ((ok >> i) & 1u) ? v[i][j] : 0.0f;
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[i][j] = ((ok >> i) & 1u) ? v[i][j] : 0.0f;
+    }
     if (KC) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -477,16 +508,15 @@ __device__ __forceinline__ void store_a(h8 *T, const StageA &st, float floor_, f
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int idx = tid + 512 * i, row = idx >> 3, kq = (idx & 7) * 4;
-        h4 hi, lo;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float ts = st.a[i][j] * sc, t = ((st.ok >> i) & 1u) ? (ts < floor_ ? floor_ : ts) : 0.0f;
-            hi[j] = (_Float16)t;
-            lo[j] = (_Float16)(t - (float)hi[j]);
-        }
+        f16g::u32x2 hi, lo;
+        unsigned a, b, c, d;
+        if (floor_ == 0.0f) f16g::split4_pk<true>(st.a[i][0], st.a[i][1], st.a[i][2], st.a[i][3], sc, a, b, c, d);
+        else f16g::split4_pk<false>(st.a[i][0], st.a[i][1], st.a[i][2], st.a[i][3], sc, a, b, c, d);
+        if (!((st.ok >> i) & 1u)) a = b = c = d = 0u;       // (a piece past the edge was loaded from a clamped, valid address)
+        hi.x = a; hi.y = b; lo.x = c; lo.y = d;
         const int o = unit(kq >> 3, row, PM) * 8 + (kq & 4);
-        *(h4 *)((_Float16 *)Ahi + o) = hi;
-        *(h4 *)((_Float16 *)Alo + o) = lo;
+        *(f16g::u32x2 *)((_Float16 *)Ahi + o) = hi;
+        *(f16g::u32x2 *)((_Float16 *)Alo + o) = lo;
     }
 }
 __device__ __forceinline__ void store_b(h8 *T, const StageB &st, int tid)

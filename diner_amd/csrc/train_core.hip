@@ -25,6 +25,7 @@ namespace diner {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 namespace train {
 namespace core {
@@ -104,6 +105,30 @@ __global__ void pack_core_kernel(const float *__restrict__ W, int64_t ld, int tr
 // This lane's 16 float4 of A for tile `tile` -> the core's `net` grid (v[NET + 4*(8*tp + j) ..]: row 32*tp + c, k = 64w + 8j + 4h ..+3).
 // Issued before a layer block: the block's first counted vmcnt wait covers them (loads return in order), so their latency is
 // spent where the partner wave of the SIMD can use the MFMA pipe, and the next S phase finds the data in registers.
+// core registers R..R+3 (x sc, relu'd if RELU: NaN kept) -> fp16 hi / lo pairs; see split4_pk in train.hip
+template <int R, bool RELU> __device__ __forceinline__ void split4_reg(float sc, unsigned &h01, unsigned &h23, unsigned &l01, unsigned &l23)
+{
+    float t0, t1, t2, t3;
+    if constexpr (RELU) {
+        unsigned long long m0, m1, m2, m3;
+        asm volatile("v_mul_f32 %4, v%c12, %16\n\tv_mul_f32 %5, v%c13, %16\n\tv_mul_f32 %6, v%c14, %16\n\tv_mul_f32 %7, v%c15, %16\n\t"
+                     "v_cmp_ngt_f32_e64 %8, 0, %4\n\tv_cmp_ngt_f32_e64 %9, 0, %5\n\tv_cmp_ngt_f32_e64 %10, 0, %6\n\tv_cmp_ngt_f32_e64 %11, 0, %7\n\t"
+                     "v_cndmask_b32_e64 %4, 0, %4, %8\n\tv_cndmask_b32_e64 %5, 0, %5, %9\n\tv_cndmask_b32_e64 %6, 0, %6, %10\n\tv_cndmask_b32_e64 %7, 0, %7, %11\n\t"
+                     "v_cvt_pk_f16_f32 %0, %4, %5\n\tv_cvt_pk_f16_f32 %1, %6, %7\n\t"
+                     "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                     : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+                     : "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3), "v"(sc));
+    } else {
+        asm volatile("v_mul_f32 %4, v%c8, %12\n\tv_mul_f32 %5, v%c9, %12\n\tv_mul_f32 %6, v%c10, %12\n\tv_mul_f32 %7, v%c11, %12\n\t"
+                     "v_cvt_pk_f16_f32 %0, %4, %5\n\tv_cvt_pk_f16_f32 %1, %6, %7\n\t"
+                     "v_fma_mixlo_f16 %2, %0, -1.0, %4 op_sel_hi:[1,0,0]\n\tv_fma_mixlo_f16 %3, %1, -1.0, %6 op_sel_hi:[1,0,0]\n\t"
+                     "v_fma_mixhi_f16 %2, %0, -1.0, %5 op_sel:[1,0,0] op_sel_hi:[1,0,0]\n\tv_fma_mixhi_f16 %3, %1, -1.0, %7 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+                     : "=&v"(h01), "=&v"(h23), "=&v"(l01), "=&v"(l23), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+                     : "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3), "v"(sc));
+    }
+}
+
 template <int REG, int OFF> __device__ __forceinline__ void load4_into(const float *ap)
 {
     asm volatile("global_load_dwordx4 v[%c1:%c2], %0, off offset:%c3" ::"v"(ap), "n"(REG), "n"(REG + 3), "n"(OFF) : "memory");
@@ -158,7 +183,6 @@ __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_num_vgpr(F16_VGP
     scale_of(g.amax_a, g.exp_a, sa, ia);
     scale_of(nullptr, g.exp_b, sb, ib);
     const float unscale = ia * ib;
-    const float floor_ = g.relu_a ? 0.0f : -__builtin_inff();
     const int64_t tiles = (g.M + TILE_M - 1) / TILE_M;
     float amax = 0.0f;
     float cs[4] = {0.0f, 0.0f, 0.0f, 0.0f};                                   // this lane's column sums (columns 64w + 4(lane & 15) ..+3, rows = lane>>4 mod 4)
@@ -180,19 +204,15 @@ __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_num_vgpr(F16_VGP
         //      `net` grid -- prefetched one tile ahead, see below -- and writes the half cell (4 halfs) of both planes: the layout
         //      store_relu() of the inference kernel writes
         sfor<0, 16>([&](auto TJ) {
-            constexpr int tp = TJ.value / 8, j = TJ.value % 8;
-            h4 hi, lo;
-            constexpr int r0 = NET + 4 * TJ.value;
-            const float a4[4] = {acc_read<r0>(), acc_read<r0 + 1>(), acc_read<r0 + 2>(), acc_read<r0 + 3>()};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float ts = a4[q] * sa, t = ts < floor_ ? floor_ : ts;   // (NaN stays NaN)
-                hi[q] = (_Float16)t;
-                lo[q] = (_Float16)(t - (float)hi[q]);
-            }
+            constexpr int tp = TJ.value / 8, j = TJ.value % 8, r0 = NET + 4 * TJ.value;
+            u32x2 hi, lo;
+            unsigned a, b, cc, d;
+            if (g.relu_a) split4_reg<r0, true>(sa, a, b, cc, d);
+            else split4_reg<r0, false>(sa, a, b, cc, d);
+            hi.x = a; hi.y = b; lo.x = cc; lo.y = d;
             char *p = img + (wave * 8 + j) * 2048 + (tp * 32 + c) * 16 + 8 * h;
-            *(h4 *)p = hi;
-            *(h4 *)(p + 1024) = lo;
+            *(u32x2 *)p = hi;
+            *(u32x2 *)(p + 1024) = lo;
         });
         prefetch_a(g, tile + gridDim.x < tiles ? tile + gridDim.x : tile, wave, c, h);   // the next tile's A lands during this tile's GEMM
 #ifdef DINER_CORE_TRACE
