@@ -188,7 +188,7 @@ def main(argv=None):
     import torch
     sys.path.insert(0, str(ROOT))
     from synthetic import synth
-    from diner_amd.dist import all_gather_tiles, shard_bounds
+    from diner_amd.dist import OverlappedGather, all_gather_tiles, shard_bounds
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -244,10 +244,13 @@ def main(argv=None):
         my_poses = [0 if strong else rank % n_poses]
     rays_by_pose = {pi: rays_of_pose(pi)[:, lo:hi].contiguous() for pi in my_poses}
     rpc = args.rays_per_call if args.rays_per_call > 0 else n_mine
-    tile = torch.empty((n_mine, 4), dtype=torch.float32, device=dev)
     n_gathered = NR if strong else world * NR
+    # the frame's [rays,4] tiles are exchanged with ONE all-gather per frame, double-buffered: it travels while the next frame renders
+    og = OverlappedGather(n_gathered, world, rank, 4, dev)
+    assert og.n_mine == n_mine
 
     def render_into_tile(rays):
+        tile = og.tile()
         o = 0
         for ch in torch.split(rays, rpc, dim=1):
             n = ch.shape[1]
@@ -262,7 +265,7 @@ def main(argv=None):
     def step(i):
         pi = my_poses[0] if len(my_poses) == 1 else (i if strong else i * world + rank) % n_poses
         render_into_tile(rays_by_pose[pi])
-        return all_gather_tiles(tile, n_gathered, world)  # one RCCL all-gather of the [rays,4] tiles per frame
+        return og.submit()  # starts this frame's all-gather (RCCL), hands back the previous frame
 
     def fence():
         if not stub:
@@ -274,13 +277,15 @@ def main(argv=None):
 
     with torch.no_grad():
         for i in range(args.warmup):
-            frame = step(i)
+            step(i)
+        og.flush()
         if rend is not None:
             rend.stage_events = []
         fence()
         t0 = time.perf_counter()
         for i in range(args.steps):
-            frame = step(args.warmup + i)
+            step(args.warmup + i)
+        frame = og.flush()          # the last frame's gather is inside the timed region
         fence()
         elapsed = time.perf_counter() - t0
         events = []

@@ -45,6 +45,57 @@ def all_gather_tiles(tile: torch.Tensor, n_total: int, world: int, group=None) -
     return torch.cat(parts, 0)
 
 
+class OverlappedGather:
+    """The §8(e) overlap: double-buffered tiles, so that the all-gather of frame i travels (RCCL's own stream) while frame i+1
+    renders.  ``tile()`` is the buffer to render the current frame's ``[n_rank, C]`` rows into; ``submit()`` starts its
+    asynchronous all-gather and returns the PREVIOUS frame, complete, as ``[n_total, C]`` (None for the first);
+    ``flush()`` returns the last one.  Uneven ranges are padded inside the buffers (no copy per frame)."""
+
+    def __init__(self, n_total: int, world: int, rank: int, channels: int, device, dtype=torch.float32, group=None):
+        self.n_total, self.world, self.group = n_total, world, group
+        lo, hi = shard_bounds(n_total, world, rank)
+        self.n_mine = hi - lo
+        q, r = divmod(n_total, world)
+        self.n_max = q + (1 if r else 0)
+        self._tiles = [torch.zeros((self.n_max, channels), dtype=dtype, device=device) for _ in range(2)]
+        self._outs = [torch.empty((world * self.n_max, channels), dtype=dtype, device=device) for _ in range(2)]
+        self._work = [None, None]
+        self._cur = 0
+        self._inflight = None          # buffer index of the frame whose gather is travelling
+
+    def tile(self) -> torch.Tensor:
+        return self._tiles[self._cur][:self.n_mine]
+
+    def _finish(self, b):
+        if self._work[b] is not None:
+            self._work[b].wait()
+            self._work[b] = None
+        if self.world == 1:
+            return self._tiles[b][:self.n_mine]
+        out = self._outs[b]
+        if self.n_total == self.world * self.n_max:
+            return out
+        parts = []
+        for k in range(self.world):
+            lo, hi = shard_bounds(self.n_total, self.world, k)
+            parts.append(out[k * self.n_max:k * self.n_max + (hi - lo)])
+        return torch.cat(parts, 0)
+
+    def submit(self):
+        b = self._cur
+        if self.world > 1:
+            self._work[b] = dist.all_gather_into_tensor(self._outs[b], self._tiles[b], group=self.group, async_op=True)
+        prev = None if self._inflight is None else self._finish(self._inflight)
+        self._inflight, self._cur = b, 1 - b
+        return prev
+
+    def flush(self):
+        if self._inflight is None:
+            return None
+        frame, self._inflight = self._finish(self._inflight), None
+        return frame
+
+
 def render_frame_sharded(render_fn: Callable[[torch.Tensor], torch.Tensor], rays: torch.Tensor,
                          world: int, rank: int, group=None) -> torch.Tensor:
     """Strong-scaling frame render: this rank renders its contiguous range of ``rays`` [1,NR,8]

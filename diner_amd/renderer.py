@@ -107,6 +107,10 @@ class NeRFRendererDGS(torch.nn.Module):
         # commute; diner_pack_linz_maps).  Costs 3x the latent's memory per encode(); set False to keep
         # lin_z as per-point GEMMs.
         self.linz_maps = True
+        # Memory budget of that hoist: the lin_z maps are 3x the latent (2.5 GB at the headline config, 16 GB for a 1024^2 x 8-view
+        # encode).  Above this many bytes the maps are NOT built and lin_z stays a per-point gather + GEMM (the kernel's LINZ = false
+        # instantiation: same results, ~1.3x the frame time); None = no limit.  See memory_report().
+        self.linz_maps_max_bytes = 64 << 30
         # informational (bench.py's executed-FLOP count): the f16x3 kernel applies block 2's fc_1 once to the mean over views
         self.fc1_on_mean = True
         self._mlp_key = None
@@ -172,7 +176,9 @@ class NeRFRendererDGS(torch.nn.Module):
         maps, poses, focal, c, ishape = self._maps_pack
         latent = self._latent_pack if need_latent else None
         linz = None
-        if need_latent and packed_mlp is not None and self.linz_maps and self.precision == "f16x3":
+        linz_bytes = 3 * latent.numel() * 4 if latent is not None else 0
+        if (need_latent and packed_mlp is not None and self.linz_maps and self.precision == "f16x3"
+                and (self.linz_maps_max_bytes is None or linz_bytes <= self.linz_maps_max_bytes)):
             zkey = (self._latent_gen, self._mlp_gen)   # generations of the two packs the maps were computed from
             if zkey != self._linz_key:
                 SB, NV, h, w, Cc = latent.shape
@@ -196,6 +202,30 @@ class NeRFRendererDGS(torch.nn.Module):
         sc.latent = latent.data_ptr() if latent is not None else None
         sc.linz_maps = linz.data_ptr() if linz is not None else None
         return sc, (maps, poses, focal, c, latent, linz)
+
+    def memory_report(self, model=None, rays_per_call=None, n_views=None):
+        """Bytes of device memory this renderer holds / will take, so that the appetite is a number and not a surprise:
+        ``cached`` = what the pack caches hold right now (packed maps, NHWC latent, lin_z maps, packed MLP); with ``rays_per_call``
+        (and ``n_views``, default: the cached scene's) also ``per_call`` = workspace + outputs of one inference ``forward`` and
+        ``training_step`` = the activations the differentiable path keeps alive between forward and backward
+        (diner_amd/training.py: every layer's input in fp32, 24 GB for 4096 rays x 40 samples x 4 views)."""
+        nb = lambda t: 0 if t is None else t.numel() * t.element_size()
+        maps = self._maps_pack[0] if self._maps_pack is not None else None
+        rep = {"cached": {"maps": nb(maps), "latent_nhwc": nb(self._latent_pack), "linz_maps": nb(self._linz_pack), "mlp_packed": nb(self._mlp_pack)}}
+        rep["cached"]["total"] = sum(rep["cached"].values())
+        rep["linz_maps_max_bytes"] = self.linz_maps_max_bytes
+        if rays_per_call is not None:
+            NV = n_views if n_views is not None else (maps.shape[1] if maps is not None else 1)
+            K, P = int(self.n_samples), int(rays_per_call) * int(self.n_samples)
+            ws = int(_lib.lib().diner_render_workspace_floats(1, int(rays_per_call), K, NV, _lib.PRECISIONS[self.precision])) * 4
+            rep["per_call"] = {"workspace": ws, "outputs": int(rays_per_call) * (4 + K) * 4}
+            rows = NV * P
+            # forward keeps: in56 + zlat + taps per (view, point); x, net of the 3 per-view blocks; the post-mean tensors per point
+            rep["training_step"] = {"per_view_rows": rows,
+                                    "saved_activations": rows * 4 * (56 + 512 + 8 + 2 * 3 * 512) + P * 4 * (2 * 2 * 512 + 512 + 4),
+                                    "note": "peak = saved activations + ~8 row-matrices [rows,512] fp32 of forward/backward temporaries "
+                                            "(measured: 24.5 GB at 4096 rays x 40 samples x 4 views, tools/bench_train.py)"}
+        return rep
 
     def _mlp(self, model) -> torch.Tensor:
         mlp = model.mlp_fine

@@ -82,3 +82,47 @@ def test_sharded_frame_equals_single_process(world, n_rays):
     want = _render_range(orc, sc, rays, noise, 0).numpy()
     for r in range(world):
         np.testing.assert_array_equal(got[r], want)
+
+
+def _worker_overlapped(rank, world, port, n_rays, q):
+    """three frames (different noise) through the double-buffered gather: frame i's all-gather is in flight while i+1 renders"""
+    from diner_amd.dist import OverlappedGather
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc, orc = _scene_and_oracle()
+        rays = sc.target_rays()[:, :n_rays]
+        lo, hi = shard_bounds(n_rays, world, rank)
+        og = OverlappedGather(n_rays, world, rank, 4, "cpu")
+        frames = []
+        for f in range(3):
+            noise = synth.make_noise(n_rays, NC, G, K, seed=10 + f)
+            og.tile().copy_(_render_range(orc, sc, rays[:, lo:hi], noise, lo))
+            prev = og.submit()
+            assert (prev is None) == (f == 0)
+            if prev is not None:
+                frames.append(prev.clone())
+        frames.append(og.flush().clone())
+        assert og.flush() is None
+        q.put((rank, np.stack([f.numpy() for f in frames])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_rays", [(2, 64), (3, 50)])
+def test_overlapped_gather_frames_equal_single_process(world, n_rays):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overlapped, args=(r, world, port, n_rays, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    sc, orc = _scene_and_oracle()
+    rays = sc.target_rays()[:, :n_rays]
+    want = np.stack([_render_range(orc, sc, rays, synth.make_noise(n_rays, NC, G, K, seed=10 + f), 0).numpy() for f in range(3)])
+    for r in range(world):
+        np.testing.assert_array_equal(got[r], want)

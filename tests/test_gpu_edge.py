@@ -242,3 +242,28 @@ def test_cache_holds_no_strong_reference(dev):
     m.encoder.latent = None
     gc.collect()
     assert ref() is None, "the renderer's pack cache kept the source latent alive"
+
+
+def test_linz_maps_budget_and_memory_report(dev):
+    """The lin_z feature maps (3x the latent) are only built within ``linz_maps_max_bytes``; beyond it lin_z stays a per-point
+    GEMM with the same results, and ``memory_report()`` says what the renderer holds."""
+    sc, w = make(seed=60)
+    rays = sc.target_rays()[:, 50:114]
+    K, NC, G = 16, 128, 5
+    noise = synth.make_noise(rays.shape[1], NC, G, K, seed=6)
+    from diner_amd import NeRFRendererDGS
+    from synthetic.model_stub import model_from_scene
+    m = model_from_scene(sc, w, device=dev)
+    outs = []
+    for limit in (64 << 30, 0):
+        r = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G, white_bkgd=sc.white_bkgd)
+        r.linz_maps_max_bytes = limit
+        with torch.no_grad():
+            outs.append(r(m, T(rays, dev), noise=tuple(T(n, dev) for n in noise)).fine.rgb.cpu().numpy())
+        rep = r.memory_report(m, rays_per_call=4096)
+        assert (rep["cached"]["linz_maps"] > 0) == (limit > 0)
+        if limit:
+            assert rep["cached"]["linz_maps"] == 3 * rep["cached"]["latent_nhwc"]
+        assert rep["cached"]["total"] == sum(v for k, v in rep["cached"].items() if k != "total")
+        assert rep["per_call"]["workspace"] > 0 and rep["training_step"]["saved_activations"] > 0
+    np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=1e-4)
