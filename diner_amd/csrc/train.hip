@@ -93,9 +93,10 @@ __device__ __forceinline__ void tile_store(float (*T)[LDT], const f32x4 (&v)[2],
 // Block -> output tile.  Workgroups are dealt round-robin to the 8 XCDs (id % 8), each with its own L2: the
 // column blocks of one 128-row tile (they all read the same A tile, the big streamed operand) are given to
 // consecutive workgroups of ONE XCD, so A leaves HBM once instead of once per column block.
-__device__ __forceinline__ void tile_of(const GemmArgs &g, int64_t &m0, int &n0)
+__device__ __forceinline__ void tile_of(const GemmArgs &g, int64_t &m0, int &n0, int64_t lin = -1)
 {
-    const int64_t gm = (g.M + BM - 1) / BM, lin = blockIdx.x;
+    const int64_t gm = (g.M + BM - 1) / BM;
+    if (lin < 0) lin = blockIdx.x;
     const int gn = (g.N + BN - 1) / BN;
     const int64_t full = gm / 8 * 8;
     int64_t mt, nb;
@@ -105,40 +106,48 @@ __device__ __forceinline__ void tile_of(const GemmArgs &g, int64_t &m0, int &n0)
     n0 = (int)nb * BN;
 }
 
+// LDS slot of tile row l for an operand staged by the f16x3 kernel's transposing store (f16g::tile_store<false>): the 4 x 4 index
+// transpose inside every 16-row block (an involution), which makes that store conflict-free; the accumulator rows / columns
+// come out in slot order and are mapped back here.
+__device__ __forceinline__ int slot16(int x) { return (x & ~15) | ((x & 3) << 2) | ((x >> 2) & 3); }
+
 // C layout of the 32x32 MFMA accumulators: col = lane&31, row = (i&3) + 8*(i>>2) + 4*(lane>>5)
+// PA / PB: the A / B operand tile was staged in slot order (rows / columns of the tile permuted by slot16)
+template <bool PA = false, bool PB = false>
 __device__ __forceinline__ void epilogue(const GemmArgs &g, const f32x16 (&acc)[2][2], int64_t m0, int n0, int wm, int wn, int lane,
                                          float unscale)
 {
 #pragma unroll
     for (int tb = 0; tb < 2; ++tb) {
-        const int n = n0 + wn + tb * 32 + (lane & 31);
+        const int nc = wn + tb * 32 + (lane & 31), n = n0 + (PB ? slot16(nc) : nc);
         if (n >= g.N) continue;
         const float bias = (g.bias && blockIdx.z == 0) ? g.bias[n] : 0.0f;
 #pragma unroll
         for (int ta = 0; ta < 2; ++ta) {
             // all 16 reads of the tile (old C, mask) are issued before the first dependent store: one memory
             // round trip per tile instead of one per element
-            const int64_t mb = m0 + wm + ta * 32 + 4 * (lane >> 5);
+            const int mbl = wm + ta * 32 + 4 * (lane >> 5);
+            auto row_of = [&](int i) -> int64_t { const int r = mbl + (i & 3) + 8 * (i >> 2); return m0 + (PA ? slot16(r) : r); };
             float old[16], msk[16];
 #pragma unroll
             for (int i = 0; i < 16; ++i) { old[i] = 0.0f; msk[i] = 1.0f; }
             if (g.accumulate && !g.atomic) {  // uniform branches, unconditional loads from clamped rows
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int64_t m = mb + (i & 3) + 8 * (i >> 2);
+                    const int64_t m = row_of(i);
                     old[i] = g.C[(m < g.M ? m : g.M - 1) * g.ldc + n];
                 }
             }
             if (g.S) {
 #pragma unroll
                 for (int i = 0; i < 16; ++i) {
-                    const int64_t m = mb + (i & 3) + 8 * (i >> 2);
+                    const int64_t m = row_of(i);
                     msk[i] = g.S[(m < g.M ? m : g.M - 1) * g.lds_ + n];
                 }
             }
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
-                const int64_t m = mb + (i & 3) + 8 * (i >> 2);
+                const int64_t m = row_of(i);
                 if (m >= g.M) continue;
                 float v = acc[ta][tb][i] * unscale + bias;
                 v = msk[i] > 0.0f ? v : 0.0f;
@@ -245,7 +254,9 @@ __device__ __forceinline__ unsigned tile_load(f32x4 (&v)[4], const float *__rest
             ok |= (unsigned)(l < l_end && k < k_end) << i;
             v[i] = *(const f32x4 *)(base + (l < l_end ? l : l_end - 1) * s_long + (k < k_end ? k : k_end - 4));
         } else {
-            const int64_t k = k0 + (tid & 7) * 4 + i, l = l0 + (tid >> 3) * 4;
+            // thread = (k-quad kq4 of 8, l-quad lq4 of 32); a 16-lane group = 4 k-quads x 4 consecutive l-quads (see tile_store)
+            const int kq4 = (tid & 3) | ((tid >> 4) & 4), lq4 = ((tid >> 2) & 15) | ((tid >> 3) & 16);
+            const int64_t k = k0 + kq4 * 4 + i, l = l0 + lq4 * 4;
             ok |= (unsigned)(k < k_end && l < l_end) << i;
             v[i] = *(const f32x4 *)(base + (k < k_end ? k : k_end - 1) * s_k + (l < l_end ? l : l_end - 4));
         }
@@ -314,9 +325,14 @@ __device__ __forceinline__ void tile_store(h8 *Thi, h8 *Tlo, const f32x4 (&v)[4]
             put4(Thi, Tlo, idx >> 3, (idx & 7) * 4, x[i][0], x[i][1], x[i][2], x[i][3], floor_, sc);
         }
     } else {
-        const int kq = (tid & 7) * 4, lq = (tid >> 3) * 4;
+        // The thread holds 4 (k) x 4 (l); row l + c goes to LDS slot slot16(l + c) = (l & ~15) | 4c | (lq4 & 3).  ds_write_b64 is
+        // serviced per 16 contiguous lanes on 32 banks: the group's lanes are 4 k-quads (both halves of 2 units) x 4 l-quads, and
+        // with the slots' low bits = the l-quad their 16 half-cells fall on 16 different bank pairs (before: 4-way conflicts,
+        // 60 % of the kernel's LDS cycles).  The MFMA rows then come out in slot order: epilogue<PA, PB>.
+        const int kq4 = (tid & 3) | ((tid >> 4) & 4), lq4 = ((tid >> 2) & 15) | ((tid >> 3) & 16);
+        const int kq = kq4 * 4, sl = ((lq4 * 4) & ~15) | (lq4 & 3);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) put4(Thi, Tlo, lq + c, kq, x[0][c], x[1][c], x[2][c], x[3][c], floor_, sc);
+        for (int c = 0; c < 4; ++c) put4(Thi, Tlo, sl + 4 * c, kq, x[0][c], x[1][c], x[2][c], x[3][c], floor_, sc);
     }
 }
 
@@ -331,8 +347,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs g)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int64_t m0;
     int n0;
-    tile_of(g, m0, n0);
-    const int64_t kbeg = (int64_t)blockIdx.z * g.k_chunk;
+    // Split-K launches (the dW GEMMs: 16 output tiles x 160 row chunks): the 16 workgroups of a chunk read the same 4 + 4 operand
+    // slices.  Workgroups go to the 8 XCDs round-robin by launch order, so in launch order each XCD's L2 would see one or two
+    // tiles of EVERY chunk and fetch every slice itself (4x the operand bytes from the Infinity Cache / HBM).  Re-deal the
+    // (tile, chunk) pairs so that XCD x works through whole chunks x, x + 8, ...: one fetch per slice, 3 of 4 reads hit L2.
+    int64_t bx = blockIdx.x, bz = blockIdx.z;
+    if (gridDim.z % 8 == 0 && !g.bias) {   // (the epilogue adds the bias in the workgroups with blockIdx.z == 0)
+        const int64_t id = (int64_t)blockIdx.z * gridDim.x + blockIdx.x, xcd = id % 8, j = id / 8;
+        bz = (j / gridDim.x) * 8 + xcd;
+        bx = j % gridDim.x;
+    }
+    tile_of(g, m0, n0, bx);
+    const int64_t kbeg = bz * g.k_chunk;
     const int64_t kend = kbeg + g.k_chunk < g.K ? kbeg + g.k_chunk : g.K;
     const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     float sa, ia, sb, ib;
@@ -393,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs g)
         DINER_GEMM_STEP(1)
     }
 #undef DINER_GEMM_STEP
-    epilogue(g, acc, m0, n0, wm, wn, lane, ia * ib);
+    epilogue<!AK, BNC>(g, acc, m0, n0, wm, wn, lane, ia * ib);
 }
 
 // max |x| over n floats as a bit pattern (non-negative floats order like unsigned integers); *out zeroed by the launcher
