@@ -395,7 +395,7 @@ def main(argv=None):
                 rend(model, ch)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            o = 0
+            o, tile = 0, og.tile()
             for ch in small:
                 out = rend(model, ch)
                 n = ch.shape[1]

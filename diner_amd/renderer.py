@@ -106,6 +106,11 @@ class NeRFRendererDGS(torch.nn.Module):
         # f16x3 mode: hoist lin_z from per point to per latent texel (linear map and bilinear interpolation
         # commute; diner_pack_linz_maps).  Costs 3x the latent's memory per encode(); set False to keep
         # lin_z as per-point GEMMs.
+        # Binding of the two whole-path entry points: "torch_ops" = torch.ops.diner.render / render_image (diner_amd/ops.py, the
+        # torch C++ extension north_star names), "ctypes" = the C ABI directly.  Same C functions either way; the build-only
+        # arguments (replayed noise, stage events) always take the ctypes route.  Default: the ops when the extension is built.
+        from . import ops as _ops
+        self.binding = "torch_ops" if _ops.available() else "ctypes"
         self.linz_maps = True
         # Memory budget of that hoist: the lin_z maps are 3x the latent (2.5 GB at the headline config, 16 GB for a 1024^2 x 8-view
         # encode).  Above this many bytes the maps are NOT built and lin_z stays a per-point gather + GEMM (the kernel's LINZ = false
@@ -463,7 +468,15 @@ class NeRFRendererDGS(torch.nn.Module):
                 L, st, seed = _lib.lib(), _stream(dev), self._next_seed()
                 self._poll_status()
                 status = _ptr(self._status_word(dev))
-                if self.stage_events is None:
+                if self.stage_events is None and noise is None and self.binding == "torch_ops":
+                    from . import ops as _ops
+                    maps_t, poses_t, focal_t, c_t, latent_t, linz_t = _keep
+                    rgb, depth, w_ = _ops.load().render(maps_t, poses_t, focal_t, c_t, latent_t, linz_t, packed, r, sc.image_w, sc.image_h,
+                                                        sc.feature_padding, sc.num_freqs, sc.freq_factor, cfg.n_candidates, cfg.n_samples,
+                                                        cfg.n_gaussian, cfg.depth_diff_max, bool(self.white_bkgd), prec, seed - (1 << 64) if seed >= (1 << 63) else seed,
+                                                        bool(want_weights), self._status_word(dev))
+                    weights = w_ if want_weights else None
+                elif self.stage_events is None:
                     check(L.diner_render(C.byref(sc), _ptr(packed), _ptr(r), NR, C.byref(cfg), int(bool(self.white_bkgd)),
                                          prec, _ptr(u_c), _ptr(n_g), _ptr(u_f), seed, _ptr(ws), _ptr(rgb), _ptr(depth),
                                          _ptr(weights), status, st), "diner_render")
@@ -513,8 +526,17 @@ class NeRFRendererDGS(torch.nn.Module):
         rgb = torch.empty((SB, H * W, 3), dtype=torch.float32, device=dev)
         depth = torch.empty((SB, H * W), dtype=torch.float32, device=dev)
         self._poll_status()
-        check(L.diner_render_image(C.byref(sc), _ptr(packed), C.byref(cam), C.byref(cfg), int(bool(self.white_bkgd)), prec, self._next_seed(),
-                                   _ptr(ws), None, _ptr(rgb), _ptr(depth), None, _ptr(self._status_word(dev)), _stream(dev)), "diner_render_image")
+        seed = self._next_seed()
+        if self.binding == "torch_ops":
+            from . import ops as _ops
+            maps_t, poses_t, focal_t, c_t, latent_t, linz_t = _keep
+            rgb, depth = _ops.load().render_image(maps_t, poses_t, focal_t, c_t, latent_t, linz_t, packed, E, Ki, zn, zf, int(H), int(W), sc.image_w,
+                                                  sc.image_h, sc.feature_padding, sc.num_freqs, sc.freq_factor, cfg.n_candidates, cfg.n_samples,
+                                                  cfg.n_gaussian, cfg.depth_diff_max, bool(self.white_bkgd), prec,
+                                                  seed - (1 << 64) if seed >= (1 << 63) else seed, self._status_word(dev))
+        else:
+            check(L.diner_render_image(C.byref(sc), _ptr(packed), C.byref(cam), C.byref(cfg), int(bool(self.white_bkgd)), prec, seed,
+                                       _ptr(ws), None, _ptr(rgb), _ptr(depth), None, _ptr(self._status_word(dev)), _stream(dev)), "diner_render_image")
         self._after_launch(dev, sync=self.finite_check != "off")    # once per frame: a NaN image never leaves this function
         rgb = rgb.view(SB, H, W, 3).permute(0, 3, 1, 2)
         if return_depth:
