@@ -141,7 +141,7 @@ def host_cores():
     return n
 
 
-KERNEL_SOURCES = ("points_mlp_f16.hip", "f16_core.inc", "gen_f16_core.py", "points_mlp.hip", "common.hpp", "Makefile")
+KERNEL_SOURCES = ("points_mlp_f16.hip", "f16_core16.inc", "gen_f16_core.py", "points_mlp.hip", "common.hpp", "Makefile")
 
 
 def kernel_source_digest() -> str:

@@ -40,6 +40,7 @@ import sys
 CAP = 96                                        # set by main(): 256 - 128 - 16 * RING
 PRIO = 0                                        # --prio=N: s_setprio N for the S phases, 0 inside the layer blocks
 SPIN_LIMIT = 1 << 18                            # polls before a flow-mode wait gives up (~25 ms; a real wait lasts microseconds)
+SHAPE = 32                                      # --shape=16: v_mfma_f32_16x16x32_f16 (Block16), default v_mfma_f32_32x32x16_f16
 PRIO_B = 0                                      # --priob=N: GEMM priority of waves 4-7 (waves 0-3: 0)
 WBITS = ""                                      # --wbits=nt|sc0|...: cache-policy bits of the weight-stream loads
 STAMPS = False                                  # --stamps: diagnostic layer blocks only (namespace of --ns), 6 s_memtime stamps each (tools/trace_f16.py)
@@ -182,7 +183,8 @@ class Block:
 
     def emit(self):
         D = self.D
-        self.e(f"v_add_u32 %[voff], {(D - 1) * 2048}, %[loff]")      # k-blocks 0..D-2 of this layer are already in the ring
+        step = 4096 if isinstance(self, Block16) else 2048
+        self.e(f"v_add_u32 %[voff], {(D - 1) * step}, %[loff]")      # k-blocks 0..D-2 of this layer are already in the ring
         if PRIO:
             self.e("s_setprio 0")                                     # GEMM at low priority: the partner's S phase (VALU, LDS, gather) goes first
             if PRIO_B:                                                # ... and waves 4-7 (the critical path: they never wait) ahead of waves 0-3
@@ -227,6 +229,85 @@ class Block:
         if PRIO:
             self.e(f"s_setprio {PRIO}")                               # the glue code that follows (this wave's S phase) outranks the partner's MFMAs
         return self.lines
+
+
+class Block16(Block):
+    """The same layer block on v_mfma_f32_16x16x32_f16 (--shape=16).  Why: at the chip's power limit the 16x16x32 shape sustains a
+    higher clock than 32x32x16 at equal cycles per FLOP (MI355X_MICROARCH.md: 1.12-1.15x the FLOP/s), and this kernel is energy-bound.
+
+    Accumulators: 16 tiles of 16 features x 16 points, 4 registers each: register i of tile (tf, tp) = feature 64w + 16tf + 4q + i of point
+    16tp + c16, lane = 16q + c16 (v[CAP + base + 4 (4 tf + tp) + i]).
+    A k-step is 32 k = two half-steps: half j works on feature tiles 2j, 2j + 1 with ring slot j (16 registers: [tf2][hi/lo] x 4) for all 4
+    point tiles -- so the ring keeps its size and its one-half-step prefetch distance -- and the 8 activation fragments of the k-step
+    (point tile x hi/lo, 32 registers, ONE set) are reloaded on the fly: in half 1, as soon as a point tile's 6 MFMAs have been issued,
+    its two fragments are re-read for the next k-step (18 MFMAs = 288+ cycles ahead of their first use).
+    Weight stream of a wave: ONE sequence of half-steps, 4 KiB each: [tf2][hi/lo][lane][8 halfs], lane = 16 kq + r holds
+    W[feature 16 (2j + tf2) + r][k = 32 kstep + 8 kq ..+7].  nkb1 / nkb2 count k-steps."""
+
+    def __init__(self, name, acc_base, nks1, nks2, D, region1_off=65536):
+        assert D == 2 and nks1 > 0
+        self.name, self.base, self.nkb1, self.nkb2, self.D = name, acc_base, nks1, nks2, D
+        self.region1_off = region1_off
+        self.lines = []
+        self.nlabel = 0
+
+    def acc16(self, tf, tp):
+        lo = CAP + self.base + 4 * (4 * tf + tp)
+        return f"v[{lo}:{lo + 3}]"
+
+    @staticmethod
+    def fr(tp, part):
+        return f"%[f{tp // 2}{(tp % 2) * 2 + part}]"
+
+    def loads(self, slot):
+        for i in range(4):                                            # (tf2, part) = (i >> 1, i & 1)
+            if not self.noload:
+                self.e(f"global_load_dwordx4 {ring(slot, i >> 1, i & 1)}, %[voff], %[w0] offset:{1024 * i}{WBITS}")
+        self.e("v_add_u32 %[voff], 4096, %[voff]")
+
+    def switch_to_next(self):
+        self.e("s_mov_b64 %[w0], %[nw0]")
+        self.e("v_mov_b32 %[voff], %[loff]")
+
+    def frag_read(self, tp, imm=0):
+        for part in range(2):
+            self.e(f"ds_read_b128 {self.fr(tp, part)}, %[ab] offset:{imm + 256 * tp + 1024 * part}")
+
+    def mfmas16(self, j, tp):
+        for wpart, fpart in ((1, 0), (0, 1), (0, 0)):                 # W_lo*a_hi, W_hi*a_lo, W_hi*a_hi
+            for tf2 in range(2):
+                a = self.acc16(2 * j + tf2, tp)
+                self.e(f"v_mfma_f32_16x16x32_f16 {a}, {ring(j, tf2, wpart)}, {self.fr(tp, fpart)}, {a}")
+
+    def body(self, tail, switch):
+        for j in range(2):
+            self.loads((j + 1) % 2)                                   # the next half-step's weights into the slot just used up
+            if switch and j == 0:
+                self.switch_to_next()
+            if j == 1 and not tail:
+                self.e("v_add_u32 %[ab], 8192, %[ab]")               # the next k-step's fragments (this one's reads are all issued)
+            self.e("s_waitcnt vmcnt(4)")                              # this half-step's weights: all but the 4 loads just issued
+            for tp in range(4):
+                if j == 0:
+                    self.e(f"s_waitcnt lgkmcnt({6 - 2 * tp})")       # fragments arrive in issue order, two per point tile
+                self.mfmas16(j, tp)
+                if j == 1 and not tail:
+                    self.frag_read(tp)                                # rolling reload: needed again 18 MFMAs from here
+
+    def half(self, nks, region, last_half):
+        self.e(f"v_add_u32 %[ab], {self.region1_off * region}, %[ab0]")
+        for tp in range(4):
+            self.frag_read(tp)                                        # the half's first k-step, behind the barrier / arrival wait
+        if nks > 1:
+            lbl = f"L{self.nlabel}_%="
+            self.nlabel += 1
+            self.e(f"s_mov_b32 %[cnt], {nks - 1}")
+            self.e(f"{lbl}:")
+            self.body(tail=False, switch=False)
+            self.e("s_sub_u32 %[cnt], %[cnt], 1")
+            self.e("s_cmp_lg_u32 %[cnt], 0")
+            self.e(f"s_cbranch_scc1 {lbl}")
+        self.body(tail=True, switch=last_half)
 
 
 def clobbers(D):
@@ -323,7 +404,21 @@ def gather_cxx(D, GQ=3):
         fin.append("s_nop 1")                                         # TT is rewritten by the next group's first v_mul: the store must have read it
       # ---- read back in the accumulator layout and add
       fin.append("s_waitcnt lgkmcnt(0)")
-      for tn in range(2):
+      if SHAPE == 16:
+        # lane = 16q + c16: float4 4tf + q of points 16tp + c16 (rows 4096 bytes apart); %[hp] = q ^ c16, %[rb] = staging row of point c16
+        for tf in range(4):
+            fin.append(f"v_xor_b32 %[a0], {4 * tf}, %[hp]")
+            fin.append("v_lshl_add_u32 %[a0], %[a0], 4, %[rb]")
+            tmp = (TO, TW, TT, RD)
+            for tp in range(4):
+                fin.append(f"ds_read_b128 {q4(tmp[tp])}, %[a0] offset:{4096 * tp}")
+            fin.append("s_waitcnt lgkmcnt(0)")
+            for tp in range(4):
+                xr = CAP + X_OFF + 4 * (4 * tf + tp)
+                for j in range(4):
+                    fin.append(f"v_add_f32 v{xr + j}, v{xr + j}, v{tmp[tp] + j}")
+      else:
+       for tn in range(2):
         for g in range(4):
             K = tn * 8 + 2 * g
             fin.append(f"v_xor_b32 %[a0], {K}, %[hp]")
@@ -416,7 +511,7 @@ __device__ __forceinline__ bool flow_wait(unsigned addr, unsigned target)
 def prologue(D):
     """Fill the ring with k-blocks 0..D-2 of the first layer (once per kernel; afterwards every layer block
     prefetches its successor's first k-blocks)."""
-    b = Block("prologue", 0, D, 0, D)
+    b = (Block16 if SHAPE == 16 else Block)("prologue", 0, D, 0, D)
     b.e("v_mov_b32 %[voff], %[loff]")
     keep, b.noload = b.noload, False
     for j in range(D if keep else D - 1):                # the no-load ablation still starts from real weights in every slot
@@ -442,7 +537,12 @@ def main():
     global CAP, PRIO
     CAP = 256 - 128 - 16 * D
     PRIO = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--prio=')), 0)
-    global FLOW, STAMPS, WBITS, PRIO_B
+    global FLOW, STAMPS, WBITS, PRIO_B, SHAPE
+    SHAPE = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--shape=')), 32)
+    assert SHAPE in (16, 32)
+    B_ = Block16 if SHAPE == 16 else Block
+    NK = 8 if SHAPE == 16 else 16                  # k-steps (32 k) / k-blocks (16 k) per half of a 512-wide layer
+    NKI = 1 if SHAPE == 16 else 2                  # ... of lin_in (64 inputs)
     PRIO_B = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--priob=')), 0)
     WBITS = next((" " + a.split("=", 1)[1].replace(",", " ") for a in sys.argv[1:] if a.startswith("--wbits=")), "")
     FLOW = '--flow' in sys.argv
@@ -452,9 +552,9 @@ def main():
         out = [f"// GENERATED by gen_f16_core.py {' '.join(sys.argv[1:])} -- do not edit.  Diagnostic twins of the layer blocks: the same code plus 6 clock\n"
                f"// stamps (entry | region 0 ready | G1 done | region 1 ready | G2 done | operand rows free), used by the TRACE kernel only.\n"
                f"namespace {ns} {{\nstruct Stamps {{ unsigned long long t[6]; }};\n"]
-        out.append(cxx(Block("layer_x_full", X_OFF, 16, 16, D)))
-        out.append(cxx(Block("layer_net_full", NET_OFF, 16, 16, D)))
-        out.append(cxx(Block("layer_x_in", X_OFF, 2, 2, D, region1_off=8192)))
+        out.append(cxx(B_("layer_x_full", X_OFF, NK, NK, D)))
+        out.append(cxx(B_("layer_net_full", NET_OFF, NK, NK, D)))
+        out.append(cxx(B_("layer_x_in", X_OFF, NKI, NKI, D, region1_off=8192)))
         out.append("}  // namespace " + ns + "\n")
         sys.stdout.write("\n".join(out))
         return
@@ -462,16 +562,17 @@ def main():
 {"namespace " + ns + " {" if ns else "#pragma once"}
 // generator arguments: {" ".join(sys.argv[1:])}
 constexpr int F16_RING = {D};
+constexpr int F16_SHAPE = {SHAPE};    // MFMA shape of the core: 32 = 32x32x16, 16 = 16x16x32 (accumulator layout, weight stream and fragment addressing differ)
 constexpr int F16_VGPR_CAP = {CAP};   // hipcc's share (amdgpu_num_vgpr); the core owns v[{CAP}:255]
 constexpr int F16_X = {CAP + X_OFF}, F16_NET = {CAP + NET_OFF};   // first register of the two accumulator grids
 """]
     out.append(sync_struct())
     out.append(prologue(D))
-    out.append(cxx(Block("layer_x_full", X_OFF, 16, 16, D)))
-    out.append(cxx(Block("layer_net_full", NET_OFF, 16, 16, D)))
+    out.append(cxx(B_("layer_x_full", X_OFF, NK, NK, D)))
+    out.append(cxx(B_("layer_net_full", NET_OFF, NK, NK, D)))
     # lin_in: 64 inputs = 4 k-blocks; waves 0-3 write unit-rows 0-3 (k < 32), waves 4-7 unit-rows 4-7 (8 KiB further)
     if D == 2:   # (the ring-4 build is a probe-only variant: tools/chain_probe.hip)
-        out.append(cxx(Block("layer_x_in", X_OFF, 2, 2, D, region1_off=8192)))
+        out.append(cxx(B_("layer_x_in", X_OFF, NKI, NKI, D, region1_off=8192)))
     out.append(gather_cxx(D))
     if ns:
         out.append("}  // namespace " + ns + "\n")

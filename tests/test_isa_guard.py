@@ -20,7 +20,7 @@ CSRC = ROOT / "diner_amd" / "csrc"
 def isa(tmp_path_factory):
     if not Path(HIPCC).exists():
         pytest.skip("hipcc not available")
-    subprocess.run(["make", "-C", str(CSRC), "f16_core.inc"], check=True, capture_output=True)
+    subprocess.run(["make", "-C", str(CSRC), "f16_core.inc", "f16_core16.inc", "f16_core16_trace.inc"], check=True, capture_output=True)
     asm = tmp_path_factory.mktemp("isa") / "points_mlp_f16.s"
     subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-unroll-loops", "-Wno-inline-asm", "-S",
                     "--cuda-device-only", "-o", str(asm), str(CSRC / "points_mlp_f16.hip")], check=True, capture_output=True, timeout=900)
@@ -28,19 +28,24 @@ def isa(tmp_path_factory):
 
 
 def _cap():
-    m = re.search(r"constexpr int F16_VGPR_CAP = (\d+);", (CSRC / "f16_core.inc").read_text())
+    m = re.search(r"constexpr int F16_VGPR_CAP = (\d+);", (CSRC / "f16_core16.inc").read_text())
     return int(m.group(1))
 
 
 def test_generated_core_is_current():
-    """f16_core.inc in the tree is what the generator produces (the Makefile regenerates it; the file is committed so that
-    the kernel source reads complete)."""
-    args = re.search(r"// generator arguments: (.*)", (CSRC / "f16_core.inc").read_text()).group(1).split()
-    out = subprocess.run(["python3", str(CSRC / "gen_f16_core.py"), *args], check=True, capture_output=True, text=True).stdout
-    assert out == (CSRC / "f16_core.inc").read_text()
-    # the diagnostic twins (TRACE kernel only): the same blocks with clock stamps
+    """The generated cores in the tree are what the generator produces (the Makefile regenerates them; the files are committed so
+    that the kernel sources read complete): f16_core16.inc (v_mfma_f32_16x16x32_f16: the inference kernel) with its stamped twin
+    (TRACE instantiation only), and f16_core.inc (32x32x16: train_core.hip, tools/chain_probe.hip)."""
+    for name, extra in (("f16_core16.inc", []), ("f16_core.inc", [])):
+        text = (CSRC / name).read_text()
+        args = re.search(r"// generator arguments: (.*)", text).group(1).split()
+        assert ("--shape=16" in args) == (name == "f16_core16.inc")
+        out = subprocess.run(["python3", str(CSRC / "gen_f16_core.py"), *args], check=True, capture_output=True, text=True).stdout
+        assert out == text, name
+    args = re.search(r"// generator arguments: (.*)", (CSRC / "f16_core16.inc").read_text()).group(1).split()
     out = subprocess.run(["python3", str(CSRC / "gen_f16_core.py"), *args, "--ns=tr", "--stamps"], check=True, capture_output=True, text=True).stdout
-    assert out == (CSRC / "f16_core_trace.inc").read_text()
+    assert out == (CSRC / "f16_core16_trace.inc").read_text()
+    assert "v_mfma_f32_16x16x32_f16" in (CSRC / "f16_core16.inc").read_text() and "v_mfma_f32_32x32x16_f16" in (CSRC / "f16_core.inc").read_text()
 
 
 def test_compiler_stays_out_of_the_core_registers(isa):
