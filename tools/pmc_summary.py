@@ -35,7 +35,7 @@ def main():
     out.mkdir(parents=True, exist_ok=True)
     tag = f"{a.config}_{a.precision}"
     # ---- kernel stats
-    ks = sorted(glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv")))
+    ks = sorted(glob.glob(str(src / "kt" / "*" / "*_kernel_stats.csv")), key=os.path.getmtime)   # newest run of the pass
     if ks:
         rows = list(csv.DictReader(open(ks[-1])))
         with open(out / f"kernel_stats_{tag}.csv", "w", newline="") as f:
@@ -45,15 +45,14 @@ def main():
                 w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
         print("wrote", out / f"kernel_stats_{tag}.csv")
     # ---- counters
-    pmc = defaultdict(lambda: defaultdict(list))
-    for p in glob.glob(str(src / "*" / "*" / "*_counter_collection.csv")):
-        for r in csv.DictReader(open(p)):
-            k = short(r["Kernel_Name"])
-            if k.startswith("diner::") or "points_mlp" in k:
-                pmc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
     # a dispatch reports one row per counter instance: sum the instances of a dispatch, average over dispatches
     res = {}
+    newest = {}   # gpurun merges every run's files into the same local directory: per pass keep the newest run only
     for p in glob.glob(str(src / "*" / "*" / "*_counter_collection.csv")):
+        d = Path(p).parents[1].name
+        if d not in newest or os.path.getmtime(p) > os.path.getmtime(newest[d]):
+            newest[d] = p
+    for p in sorted(newest.values()):
         per = defaultdict(lambda: defaultdict(float))
         for r in csv.DictReader(open(p)):
             k = short(r["Kernel_Name"])
