@@ -40,6 +40,7 @@ import sys
 CAP = 96                                        # set by main(): 256 - 128 - 16 * RING
 PRIO = 0                                        # --prio=N: s_setprio N for the S phases, 0 inside the layer blocks
 SPIN_LIMIT = 1 << 18                            # polls before a flow-mode wait gives up (~25 ms; a real wait lasts microseconds)
+ORDER = "prod"                                  # --order=acc|prod: MFMA order inside a point tile of a half-step (shape 16)
 SHAPE = 32                                      # --shape=16: v_mfma_f32_16x16x32_f16 (Block16), default v_mfma_f32_32x32x16_f16
 PRIO_B = 0                                      # --priob=N: GEMM priority of waves 4-7 (waves 0-3: 0)
 WBITS = ""                                      # --wbits=nt|sc0|...: cache-policy bits of the weight-stream loads
@@ -274,10 +275,11 @@ class Block16(Block):
             self.e(f"ds_read_b128 {self.fr(tp, part)}, %[ab] offset:{imm + 256 * tp + 1024 * part}")
 
     def mfmas16(self, j, tp):
-        for wpart, fpart in ((1, 0), (0, 1), (0, 0)):                 # W_lo*a_hi, W_hi*a_lo, W_hi*a_hi
-            for tf2 in range(2):
-                a = self.acc16(2 * j + tf2, tp)
-                self.e(f"v_mfma_f32_16x16x32_f16 {a}, {ring(j, tf2, wpart)}, {self.fr(tp, fpart)}, {a}")
+        prods = ((1, 0), (0, 1), (0, 0))                              # W_lo*a_hi, W_hi*a_lo, W_hi*a_hi (small terms first)
+        pairs = [(p, tf2) for tf2 in range(2) for p in prods] if ORDER == "acc" else [(p, tf2) for p in prods for tf2 in range(2)]
+        for (wpart, fpart), tf2 in pairs:                             # --order=acc: the 3 products of an accumulator back to back
+            a = self.acc16(2 * j + tf2, tp)
+            self.e(f"v_mfma_f32_16x16x32_f16 {a}, {ring(j, tf2, wpart)}, {self.fr(tp, fpart)}, {a}")
 
     def body(self, tail, switch):
         for j in range(2):
@@ -537,7 +539,8 @@ def main():
     global CAP, PRIO
     CAP = 256 - 128 - 16 * D
     PRIO = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--prio=')), 0)
-    global FLOW, STAMPS, WBITS, PRIO_B, SHAPE
+    global FLOW, STAMPS, WBITS, PRIO_B, SHAPE, ORDER
+    ORDER = next((a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--order=')), "prod")
     SHAPE = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--shape=')), 32)
     assert SHAPE in (16, 32)
     B_ = Block16 if SHAPE == 16 else Block
