@@ -95,10 +95,11 @@ class Block:
         b = self.base
         hi = [f"%[f{buf}0]", f"%[f{buf}1]"]
         lo = [f"%[f{buf}2]", f"%[f{buf}3]"]
-        for wpart, frags in ((1, hi), (0, lo), (0, hi)):   # W_lo*a_hi, W_hi*a_lo, W_hi*a_hi
-            for tn in range(2):
-                for tp in range(2):
-                    self.e(f"v_mfma_f32_32x32x16_f16 {acc(b, tn, tp)}, {ring(slot, tn, wpart)}, {frags[tp]}, {acc(b, tn, tp)}")
+        prods = ((1, hi), (0, lo), (0, hi))                # W_lo*a_hi, W_hi*a_lo, W_hi*a_hi
+        order = [(p, tn, tp) for tn in range(2) for tp in range(2) for p in prods] if ORDER == "acc" else \
+                [(p, tn, tp) for p in prods for tn in range(2) for tp in range(2)]
+        for (wpart, frags), tn, tp in order:               # --order=acc: the 3 products of an accumulator back to back (see Block16)
+            self.e(f"v_mfma_f32_32x32x16_f16 {acc(b, tn, tp)}, {ring(slot, tn, wpart)}, {frags[tp]}, {acc(b, tn, tp)}")
 
     # ---- synchronisation -------------------------------------------------------------------------------------------------
     # barrier mode: s_barrier.  flow mode: four monotonic counters in LDS at %[ctr] (byte offsets 0 SA, 4 SB, 8 G1, 12 G2):
