@@ -40,6 +40,7 @@ import sys
 CAP = 96                                        # set by main(): 256 - 128 - 16 * RING
 PRIO = 0                                        # --prio=N: s_setprio N for the S phases, 0 inside the layer blocks
 SPIN_LIMIT = 1 << 18                            # polls before a flow-mode wait gives up (~25 ms; a real wait lasts microseconds)
+PRODS = "small"                                 # --prods=share: W_hi*a_lo, W_hi*a_hi, W_lo*a_hi (neighbours share an operand; probe)
 ORDER = "prod"                                  # --order=acc|prod: MFMA order inside a point tile of a half-step (shape 16)
 SHAPE = 32                                      # --shape=16: v_mfma_f32_16x16x32_f16 (Block16), default v_mfma_f32_32x32x16_f16
 PRIO_B = 0                                      # --priob=N: GEMM priority of waves 4-7 (waves 0-3: 0)
@@ -276,7 +277,7 @@ class Block16(Block):
             self.e(f"ds_read_b128 {self.fr(tp, part)}, %[ab] offset:{imm + 256 * tp + 1024 * part}")
 
     def mfmas16(self, j, tp):
-        prods = ((1, 0), (0, 1), (0, 0))                              # W_lo*a_hi, W_hi*a_lo, W_hi*a_hi (small terms first)
+        prods = ((0, 1), (0, 0), (1, 0)) if PRODS == "share" else ((1, 0), (0, 1), (0, 0))   # default: W_lo*a_hi, W_hi*a_lo, W_hi*a_hi (small terms first)
         pairs = [(p, tf2) for tf2 in range(2) for p in prods] if ORDER == "acc" else [(p, tf2) for p in prods for tf2 in range(2)]
         for (wpart, fpart), tf2 in pairs:                             # --order=acc: the 3 products of an accumulator back to back
             a = self.acc16(2 * j + tf2, tp)
@@ -540,7 +541,8 @@ def main():
     global CAP, PRIO
     CAP = 256 - 128 - 16 * D
     PRIO = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--prio=')), 0)
-    global FLOW, STAMPS, WBITS, PRIO_B, SHAPE, ORDER
+    global FLOW, STAMPS, WBITS, PRIO_B, SHAPE, ORDER, PRODS
+    PRODS = next((a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--prods=')), "small")
     ORDER = next((a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--order=')), "prod")
     SHAPE = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--shape=')), 32)
     assert SHAPE in (16, 32)
