@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X-native DINER render path: rendered rays/s.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3] [--scaling weak|strong]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--config cfg3] [--scaling auto|weak|strong]
 
 A *step* renders one full target frame per GPU through the product path
 (`diner_amd.NeRFRendererDGS.forward`: depth-guided sampler -> fused projection/gather/fusion-MLP
@@ -11,11 +11,15 @@ Multi-GPU: one process per GPU over RCCL.  `python bench.py -
 command starts its own N ranks (a fresh `python -m torch.distributed.run` child, spawned before this
 process has touched the GPU) and relays rank 0's line; under an external torch.distributed.run
 (RANK set) it is one of the ranks.  Two forms, both with the tile exchange inside the timed region:
-  --scaling weak   (default, the headline form) every rank renders its own target pose of the same
-                   scene: per-GPU work fixed, images sharded across GPUs first;
-  --scaling strong ONE frame per step: its rays are split into contiguous balanced ranges
-                   (`diner_amd.dist.shard_bounds`), every rank renders its range and the rendered
-                   [rays,4] tiles are all-gathered so that every rank holds the whole frame.
+  strong  ONE frame per step: its rays are split into N contiguous balanced ranges
+          (`diner_amd.dist.shard_bounds`), every rank renders its range and the rendered [rays,4]
+          tiles are all-gathered so that every rank holds the whole frame -- SURVEY.md §8(e)'s
+          partitioning and the north_star question (">= 6x at 8 GPUs" on one 512x512 frame);
+  weak    every rank renders its own target pose of the same scene: per-GPU work fixed, images
+          sharded across GPUs first -- §8(e)'s form for cfg4 ("full val set").
+`--scaling auto` (the default, what a bare `bench.py --gpus N` runs) is strong for cfg2 / cfg3 / cfg5 and
+weak for cfg4; the OTHER form is then timed too and printed under `other_form` in the same line, and
+`ranks_seen` lists what the process group really saw (world size, backend, every rank's device).
 
 Rank 0 prints ONE JSON line (contract in the task description) with two extra objects:
   roofline      dominant kernel (fused point/MLP kernel, MFMA-bound): algorithmic FLOP per launch
@@ -79,8 +83,10 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="cfg3", choices=sorted(CONFIGS))
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N>1: weak = one frame per GPU per step (default); strong = one frame per step split over the GPUs")
+    ap.add_argument("--scaling", default="auto", choices=["auto", "weak", "strong"],
+                    help="N>1: strong = one frame per step, its rays split over the GPUs (SURVEY 8(e); auto for cfg2/3/5); "
+                         "weak = one frame per GPU per step (auto for cfg4: images first)")
+    ap.add_argument("--no-other-form", action="store_true", help="N>1: do not also time the other scaling form")
     ap.add_argument("--rays-per-call", type=int, default=0, help="0 = whole frame in one launch (native mode); "
                     "4096 = the reference's ray_batch_size (src/models/diner.py:57)")
     ap.add_argument("--cpu-sample-rays", type=int, default=0, help="rays of the cpu_baseline sample (0 = the config's default)")
@@ -121,6 +127,12 @@ def launch_ranks(args, argv) -> int:
         print("bench.py: the ranks exited without a result line", file=sys.stderr)
         return 1
     return p.returncode
+
+
+def default_form(config: str) -> str:
+    """N>1 form of `--scaling auto` = SURVEY.md 8(e): one frame's rays split over the ranks ("strong") for cfg2 / cfg3 / cfg5,
+    images first ("weak") for cfg4, whose unit of work is a validation set of images."""
+    return "weak" if config.startswith("cfg4") else "strong"
 
 
 def flops_per_ray(K, NV):
@@ -210,10 +222,22 @@ def main(argv=None):
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-    strong = args.scaling == "strong" and world > 1
-
     cfg = CONFIGS[args.config]
     H, W, NV, K, G, NC = cfg["H"], cfg["W"], cfg["NV"], cfg["K"], cfg["G"], cfg["NC"]
+    # N>1 default = SURVEY.md 8(e): one frame's rays split over the ranks (cfg2 / cfg3 / cfg5), images first for cfg4
+    images_first = args.config.startswith("cfg4")     # (also: its steps cycle through the config's target poses)
+    strong = world > 1 and (args.scaling if args.scaling != "auto" else default_form(args.config)) == "strong"
+
+    # what the process group really is: world size and backend from torch.distributed, every rank's device gathered to all
+    me = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(),
+          "device_index": None if stub else torch.cuda.current_device(),
+          "device_name": "cpu (stub)" if stub else torch.cuda.get_device_name(dev)}
+    if world > 1:
+        seen = [None] * world
+        dist.all_gather_object(seen, me)
+        ranks_seen = {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": seen}
+    else:
+        ranks_seen = {"world_size": 1, "backend": None, "ranks": [me]}
 
     # ---- synthetic scene, resident in HBM before the timed region ------------
     scene = synth.make_scene(H, W, NV, seed=0, dataset=cfg["dataset"], with_latent=False)
@@ -230,42 +254,13 @@ def main(argv=None):
         rend.precision = args.precision
     # target poses: weak = every rank renders its own pose in every step; strong = all ranks share the step's pose
     n_poses = cfg["poses"]
-    yaws = np.linspace(-0.4, 0.45, n_poses) if args.config.startswith("cfg4") else 0.1 + 0.07 * np.arange(n_poses)
+    yaws = np.linspace(-0.4, 0.45, n_poses) if images_first else 0.1 + 0.07 * np.arange(n_poses)
 
     def rays_of_pose(pi):
         scene.target_extrinsics = synth.look_at_origin_w2c(float(yaws[pi % n_poses]), scene.meta["cam_radius"])
         return torch.from_numpy(scene.target_rays()).to(dev)  # [1, H*W, 8]
 
     NR = H * W
-    lo, hi = shard_bounds(NR, world, rank) if strong else (0, NR)
-    n_mine = hi - lo
-    my_poses = sorted({(i if strong else i * world + rank) % n_poses for i in range(args.steps + args.warmup)})
-    if not args.config.startswith("cfg4"):  # one fixed pose per rank (weak) / one pose (strong), as in round 1
-        my_poses = [0 if strong else rank % n_poses]
-    rays_by_pose = {pi: rays_of_pose(pi)[:, lo:hi].contiguous() for pi in my_poses}
-    rpc = args.rays_per_call if args.rays_per_call > 0 else n_mine
-    n_gathered = NR if strong else world * NR
-    # the frame's [rays,4] tiles are exchanged with ONE all-gather per frame, double-buffered: it travels while the next frame renders
-    og = OverlappedGather(n_gathered, world, rank, 4, dev)
-    assert og.n_mine == n_mine
-
-    def render_into_tile(rays):
-        tile = og.tile()
-        o = 0
-        for ch in torch.split(rays, rpc, dim=1):
-            n = ch.shape[1]
-            if stub:
-                tile[o:o + n] = stub_tile(ch)
-            else:
-                out = rend(model, ch)
-                tile[o:o + n, :3] = out.fine.rgb[0]
-                tile[o:o + n, 3] = out.fine.depth[0]
-            o += n
-
-    def step(i):
-        pi = my_poses[0] if len(my_poses) == 1 else (i if strong else i * world + rank) % n_poses
-        render_into_tile(rays_by_pose[pi])
-        return og.submit()  # starts this frame's all-gather (RCCL), hands back the previous frame
 
     def fence():
         if not stub:
@@ -275,38 +270,97 @@ def main(argv=None):
         if not stub:
             torch.cuda.synchronize()
 
-    with torch.no_grad():
-        for i in range(args.warmup):
-            step(i)
-        og.flush()
-        if rend is not None:
-            rend.stage_events = []
-        fence()
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            step(args.warmup + i)
-        frame = og.flush()          # the last frame's gather is inside the timed region
-        fence()
-        elapsed = time.perf_counter() - t0
-        events = []
-        if rend is not None:
-            events, rend.stage_events = rend.stage_events, None
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert frame.shape[0] == n_gathered
-    stub_ok = None
-    if stub:  # rehearsal: the gathered frame must be what one process would have produced
-        last = args.warmup + args.steps - 1
-        if strong:
-            want = stub_tile(rays_of_pose(my_poses[0] if len(my_poses) == 1 else last % n_poses))
-        else:
-            want = torch.cat([stub_tile(rays_of_pose(r % n_poses if not args.config.startswith("cfg4") else (last * world + r) % n_poses))
-                              for r in range(world)], 0)
-        stub_ok = bool(torch.equal(frame, want))
+    class Form:
+        """One scaling form of the step: which rays this rank renders, the double-buffered all-gather of the [rays,4] tiles."""
 
-    rays_per_step = NR if strong else world * NR     # rays all ranks rendered per step
+        def __init__(self, strong):
+            self.strong = strong
+            self.lo, self.hi = shard_bounds(NR, world, rank) if strong else (0, NR)
+            self.n_mine = self.hi - self.lo
+            self.poses = sorted({self.pose_of_step(i) for i in range(args.steps + args.warmup)})
+            self.rays = {pi: rays_of_pose(pi)[:, self.lo:self.hi].contiguous() for pi in self.poses}
+            self.rpc = args.rays_per_call if args.rays_per_call > 0 else self.n_mine
+            self.n_gathered = NR if strong else world * NR
+            # ONE all-gather per frame, double-buffered: it travels while the next frame renders
+            self.og = OverlappedGather(self.n_gathered, world, rank, 4, dev)
+            assert self.og.n_mine == self.n_mine
+
+        def pose_of_step(self, i, r=rank):
+            if not images_first:  # one fixed pose per rank (weak) / one pose (strong), as in round 1
+                return 0 if self.strong else r % n_poses
+            return (i if self.strong else i * world + r) % n_poses
+
+        def render_into_tile(self, rays):
+            tile = self.og.tile()
+            o = 0
+            for ch in torch.split(rays, self.rpc, dim=1):
+                n = ch.shape[1]
+                if stub:
+                    tile[o:o + n] = stub_tile(ch)
+                else:
+                    out = rend(model, ch)
+                    tile[o:o + n, :3] = out.fine.rgb[0]
+                    tile[o:o + n, 3] = out.fine.depth[0]
+                o += n
+
+        def step(self, i):
+            self.render_into_tile(self.rays[self.pose_of_step(i)])
+            return self.og.submit()  # starts this frame's all-gather (RCCL), hands back the previous frame
+
+        def timed(self):
+            """W warm-up steps, then exactly K steps between two fences; max over ranks; -> (seconds, last frame, stage events)"""
+            with torch.no_grad():
+                for i in range(args.warmup):
+                    self.step(i)
+                self.og.flush()
+                if rend is not None:
+                    rend.stage_events = []
+                fence()
+                t0 = time.perf_counter()
+                for i in range(args.steps):
+                    self.step(args.warmup + i)
+                frame = self.og.flush()          # the last frame's gather is inside the timed region
+                fence()
+                elapsed = time.perf_counter() - t0
+                events = []
+                if rend is not None:
+                    events, rend.stage_events = rend.stage_events, None
+            if world > 1:
+                t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            assert frame.shape[0] == self.n_gathered
+            return elapsed, frame, events
+
+        def stub_frame_ok(self, frame):
+            """rehearsal: the gathered frame must be what one process would have produced"""
+            last = args.warmup + args.steps - 1
+            if self.strong:
+                want = stub_tile(rays_of_pose(self.pose_of_step(last)))
+            else:
+                want = torch.cat([stub_tile(rays_of_pose(self.pose_of_step(last, r))) for r in range(world)], 0)
+            return bool(torch.equal(frame, want))
+
+        def rays_per_step(self):
+            return NR if self.strong else world * NR     # rays all ranks rendered per step
+
+    form = Form(strong)
+    elapsed, frame, events = form.timed()
+    stub_ok = form.stub_frame_ok(frame) if stub else None
+    n_mine, rpc = form.n_mine, form.rpc
+    render_into_tile, og = form.render_into_tile, form.og
+    rays_by_pose, my_poses = form.rays, form.poses
+    other = None
+    if world > 1 and not args.no_other_form:       # the other form, same steps, printed beside the headline one
+        of = Form(not strong)
+        o_elapsed, o_frame, _ = of.timed()
+        other = {"scaling": "strong" if of.strong else "weak", "value": of.rays_per_step() * args.steps / o_elapsed, "unit": "rays/s",
+                 "ms_per_step": o_elapsed / args.steps * 1e3, "rays_per_gpu_per_step": of.n_mine}
+        if stub:
+            other["stub_frame_ok"] = of.stub_frame_ok(o_frame)
+        del of, o_frame
+
+    rays_per_step = form.rays_per_step()
     result = {
         "metric": "rendered rays/sec (512x512, 4 src views, 128 samples/ray)",
         "value": rays_per_step * args.steps / elapsed,
@@ -317,6 +371,8 @@ def main(argv=None):
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "strong" if strong else "weak",
+        "other_form": other,
+        "ranks_seen": ranks_seen,
         "vs_baseline": None,
         "dtype": "f32" if args.precision == "fp32" else "f32 (GEMM operands split into fp16 hi+lo, 3 fp16 MFMAs per product, fp32 accumulate)",
         "data": "synthetic" if not stub else "stub (CPU rehearsal of the launcher, not a measurement)",

@@ -39,6 +39,40 @@ def test_self_launch_world2(scaling, config):
     total = H * W if scaling == "strong" else 2 * H * W
     assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
     assert d["unit"] == "rays/s" and d["higher_is_better"] is True and d["vs_baseline"] is None
+    # the other form is timed too and printed beside the headline one
+    o = d["other_form"]
+    assert o["scaling"] == ("weak" if scaling == "strong" else "strong") and o["stub_frame_ok"] is True
+    assert o["rays_per_gpu_per_step"] == (H * W if scaling == "strong" else H * W // 2)
+    o_total = 2 * H * W if scaling == "strong" else H * W
+    assert abs(o["value"] - o_total / (o["ms_per_step"] * 1e-3)) <= 1e-6 * o["value"]
+    # what the process group really saw
+    rs = d["ranks_seen"]
+    assert rs["world_size"] == 2 and rs["backend"] == "gloo" and [r["rank"] for r in rs["ranks"]] == [0, 1]
+    assert all("device_name" in r and "local_rank" in r for r in rs["ranks"])
+
+
+@pytest.mark.parametrize("config,want", [("tiny", "strong"), ("cfg4s", "weak")])
+def test_default_form_is_survey_8e(config, want):
+    """A bare `bench.py --gpus N` (how the driver runs it) answers north_star's question: one frame's rays split into N contiguous
+    ranges + one all-gather for the square-frame configs (cfg2 / cfg3 / cfg5 and their plumbing stand-in `tiny`), images first
+    for cfg4 (here its plumbing-size twin cfg4s) -- SURVEY.md 8(e); the loop being sharded is the reference's src/models/diner.py:85-92."""
+    extra = ["--gpus", "2"] + (["--config", config] if config != "tiny" else [])
+    p = run(*extra)
+    assert p.returncode == 0, p.stderr[-3000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.strip()][0])
+    H, W = (64, 64) if config == "tiny" else (48, 60)
+    assert d["scaling"] == want and d["stub_frame_ok"] is True
+    assert d["config"]["rays_per_gpu_per_step"] == (H * W // 2 if want == "strong" else H * W)
+    assert d["other_form"]["scaling"] != want and d["ranks_seen"]["world_size"] == 2
+
+
+def test_default_form_table():
+    """the auto rule for every BASELINE configuration, without launching anything"""
+    sys.path.insert(0, str(ROOT))
+    import bench
+    for cfg, want in dict(cfg2="strong", cfg3="strong", cfg5="strong", cfg4="weak").items():
+        a = bench.parse_args(["--gpus", "8", "--config", cfg])
+        assert a.scaling == "auto" and bench.default_form(a.config) == want
 
 
 def test_world_mismatch_is_an_error():
@@ -51,6 +85,7 @@ def test_single_process_stub():
     assert p.returncode == 0, p.stderr[-3000:]
     d = json.loads(p.stdout.strip())
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["stub_frame_ok"] is True
+    assert d["other_form"] is None and d["ranks_seen"]["world_size"] == 1
 
 
 def test_traffic_figure_is_tied_to_the_kernel_sources(monkeypatch):

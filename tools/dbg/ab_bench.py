@@ -18,6 +18,7 @@ h, w = sc.latent_hw
 latent = torch.randn((1, NV, 512, h, w), generator=torch.Generator(device=dev).manual_seed(1234), device=dev)
 m = model_from_scene(sc, synth.make_mlp_weights(7, bias_scale=0.1), device=dev, latent=latent)
 r = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G)
+r.finite_check = "off"      # (ablation variants produce garbage by design)
 rays = torch.from_numpy(sc.target_rays()).to(dev)[:, :131072]
 ts = []
 with torch.no_grad():
