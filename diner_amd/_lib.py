@@ -17,6 +17,8 @@ LIB_PATH = Path(__file__).resolve().parent / "lib" / "libdiner_hip.so"
 _FP = C.c_void_p  # device pointers travel as integers
 
 N_BLOCKS, COMBINE = 5, 3
+# the ABI version THIS binding (the argument lists in SYMBOLS below) is written against = DINER_ABI_VERSION of include/diner_hip.h
+ABI_VERSION = 2
 PRECISIONS = {"fp32": 0, "f16x3": 1}
 
 
@@ -109,6 +111,9 @@ def lib() -> C.CDLL:
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(l, name)  # AttributeError if the ABI and the header drift apart
             fn.restype, fn.argtypes = res, args
+        if l.diner_version() != ABI_VERSION:   # a stale .so (e.g. a git-ignored build from before an ABI change): never call into it
+            raise ImportError(f"{LIB_PATH} has ABI version {l.diner_version()}, this binding needs {ABI_VERSION}: rebuild it "
+                              "(`make -C diner_amd/csrc`)")
         _lib = l
     return _lib
 

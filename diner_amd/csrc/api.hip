@@ -103,7 +103,7 @@ using namespace diner;
 extern "C" {
 
 const char *diner_last_error(void) { return g_err; }
-int diner_version(void) { return 2; }
+int diner_version(void) { return DINER_ABI_VERSION; }
 
 int diner_gen_rays(const float *extrinsics, const float *intrinsics, const float *z_near, const float *z_far, int32_t B,
                    int32_t H, int32_t W, float *rays_out, void *stream)

@@ -32,6 +32,16 @@ void check_rc(int rc, const char *what)
     TORCH_CHECK(false, what, ": ", diner_last_error(), " (rc=", rc, ")");
 }
 
+// The extension is a separate file from libdiner_hip.so: one compiled against another ABI version (a stale build next to a fresh
+// library) would pass a wrong argument list.  Checked at every op entry (one call + compare).
+void check_abi()
+{
+    TORCH_CHECK(diner_version() == DINER_ABI_VERSION, "diner: libdiner_torch_ops.so was built for ABI version ", DINER_ABI_VERSION,
+                " but libdiner_hip.so is version ", diner_version(), ": rebuild the extension (diner_amd.ops.build(force=True))");
+}
+
+int64_t abi_version() { return DINER_ABI_VERSION; }
+
 DinerScene scene_of(const at::Tensor &maps, const at::Tensor &poses, const at::Tensor &focal, const at::Tensor &c, const at::Tensor &latent,
                     const c10::optional<at::Tensor> &linz, double image_w, double image_h, double feature_padding, int64_t num_freqs,
                     double freq_factor)
@@ -66,6 +76,7 @@ std::tuple<at::Tensor, at::Tensor, at::Tensor> render(const at::Tensor &maps, co
                                                       int64_t n_gaussian, double depth_diff_max, bool white_bkgd, int64_t precision, int64_t seed,
                                                       bool want_weights, const c10::optional<at::Tensor> &status)
 {
+    check_abi();
     const DinerScene s = scene_of(maps, poses, focal, c, latent, linz, image_w, image_h, feature_padding, num_freqs, freq_factor);
     const DinerSamplerCfg cfg = cfg_of(n_candidates, n_samples, n_gaussian, depth_diff_max);
     TORCH_CHECK(rays.dim() == 3 && rays.size(2) == 8 && rays.size(0) == s.SB, "diner: rays must be [SB,NR,8]");   // nerf_renderer.py:412
@@ -91,6 +102,7 @@ std::tuple<at::Tensor, at::Tensor> render_image(const at::Tensor &maps, const at
                                                 int64_t n_samples, int64_t n_gaussian, double depth_diff_max, bool white_bkgd, int64_t precision,
                                                 int64_t seed, const c10::optional<at::Tensor> &status)
 {
+    check_abi();
     const DinerScene s = scene_of(maps, poses, focal, c, latent, linz, image_w, image_h, feature_padding, num_freqs, freq_factor);
     const DinerSamplerCfg cfg = cfg_of(n_candidates, n_samples, n_gaussian, depth_diff_max);
     TORCH_CHECK(extrinsics.numel() == (int64_t)s.SB * 16 && intrinsics.numel() == (int64_t)s.SB * 9 && z_near.numel() == s.SB && z_far.numel() == s.SB,
@@ -113,6 +125,7 @@ std::tuple<at::Tensor, at::Tensor> render_image(const at::Tensor &maps, const at
 
 TORCH_LIBRARY(diner, m)
 {
+    m.def("abi_version() -> int", &abi_version);   // the DINER_ABI_VERSION this extension was compiled against
     m.def("render(Tensor maps, Tensor poses, Tensor focal, Tensor c, Tensor latent, Tensor? linz_maps, Tensor mlp_packed, Tensor rays, "
           "float image_w, float image_h, float feature_padding, int num_freqs, float freq_factor, int n_candidates, int n_samples, "
           "int n_gaussian, float depth_diff_max, bool white_bkgd, int precision, int seed, bool want_weights, Tensor? status) "

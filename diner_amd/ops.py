@@ -22,7 +22,7 @@ _loaded = False
 
 def build(force: bool = False) -> Path:
     """g++ the extension against the installed torch headers (host code only: seconds); needs libdiner_hip.so next to it."""
-    if LIB.exists() and not force and LIB.stat().st_mtime >= max(SRC.stat().st_mtime, _lib.LIB_PATH.stat().st_mtime):
+    if not force and not stale():
         return LIB
     from torch.utils import cpp_extension as ce
     inc = [f"-I{p}" for p in ce.include_paths()] + ["-I/opt/rocm/include"]
@@ -30,12 +30,34 @@ def build(force: bool = False) -> Path:
     cmd = ["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-D__HIP_PLATFORM_AMD__", "-DUSE_ROCM",
            f"-D_GLIBCXX_USE_CXX11_ABI={int(torch._C._GLIBCXX_USE_CXX11_ABI)}", *inc, str(SRC), "-o", str(LIB), *libs,
            "-ltorch", "-ltorch_cpu", "-lc10", "-lc10_hip", "-ltorch_hip", f"-L{LIB.parent}", "-ldiner_hip", "-Wl,-rpath,$ORIGIN"]
+    STAMP.unlink(missing_ok=True)
     subprocess.run(cmd, check=True)
+    STAMP.write_text(_deps_digest() + "\n")
     return LIB
 
 
+STAMP = LIB.with_suffix(".stamp")
+
+
+def _deps_digest() -> str:
+    """sha256 over what the extension is built from and links against: torch_ops.cpp, the ABI header, libdiner_hip.so itself
+    (contents, not mtimes: the snapshot that carries the build to the GPU box need not preserve times)."""
+    import hashlib
+    h = hashlib.sha256()
+    for p in (SRC, SRC.parents[2] / "include" / "diner_hip.h", _lib.LIB_PATH):
+        h.update(p.read_bytes() if p.exists() else b"<missing>")
+    return h.hexdigest()
+
+
+def stale() -> bool:
+    """True when the extension is missing or was built from / against other files than the ones present (libdiner_hip.so,
+    torch_ops.cpp, the ABI header): such a file may carry another argument list and must not be loaded."""
+    return not (LIB.exists() and STAMP.exists() and STAMP.read_text().strip() == _deps_digest())
+
+
 def available() -> bool:
-    return LIB.exists()
+    """The renderer takes the torch-ops binding only when the extension is built AND current; otherwise ctypes."""
+    return not stale()
 
 
 def load():
@@ -44,7 +66,13 @@ def load():
     if not _loaded:
         if not LIB.exists():
             raise RuntimeError(f"{LIB} is missing: run `python __graft_entry__.py` (build()) first")
-        _lib.lib()                       # libdiner_hip.so first: the extension resolves its symbols from it
+        if stale():
+            raise RuntimeError(f"{LIB} is older than libdiner_hip.so / torch_ops.cpp / diner_hip.h: rebuild it (diner_amd.ops.build())")
+        hip = _lib.lib()                 # libdiner_hip.so first: the extension resolves its symbols from it
         torch.ops.load_library(str(LIB))
+        built_for = int(torch.ops.diner.abi_version())
+        if built_for != hip.diner_version():   # (the ops check this again at every entry)
+            raise RuntimeError(f"{LIB} was built for ABI version {built_for}, libdiner_hip.so is {hip.diner_version()}: "
+                               "rebuild it (diner_amd.ops.build(force=True))")
         _loaded = True
     return torch.ops.diner

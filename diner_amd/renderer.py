@@ -61,6 +61,91 @@ class _Sources:
             for r, v, sh, t in zip(self.refs, self.versions, self.shapes, tensors))
 
 
+class _FiniteGuard:
+    """The non-finite status of the frames a renderer has issued (its own object so that a ``weakref.finalize`` of the renderer can
+    run the last check without keeping the renderer alive).  The compositing kernel ORs DINER_STATUS_NONFINITE into the device word;
+    a copy to pinned host memory + an event follow every call; ``poll`` examines the copies that have completed (all, if ``wait``)."""
+
+    unreported = []          # messages of non-finite frames found where nothing could be raised (a finalizer): raised by the next call
+
+    def __init__(self):
+        self.status = None   # device int32 word
+        self.pending = []    # [(event, pinned host word)] oldest first
+        self.precision = "f16x3"
+
+    def word(self, dev):
+        if self.status is None or self.status.device != dev:
+            self.status = torch.zeros(1, dtype=torch.int32, device=dev)
+            self.pending = []
+        return self.status
+
+    def message(self):
+        return ("diner_amd.NeRFRendererDGS: a rendered rgb-sigma sample was inf/NaN" +
+                (" -- in precision='f16x3' an MLP activation left the fp16 range (|x| >= ~1e6, see DESIGN.md); set "
+                 "renderer.precision = 'fp32' (exact fp32 MFMA) for this model" if self.precision == "f16x3" else
+                 " -- the model itself produces non-finite values for these inputs"))
+
+    def poll(self, wait=False, keep=0):
+        """examine the completed copies; with ``wait`` block for all but the ``keep`` youngest; raise if a frame went non-finite"""
+        if _FiniteGuard.unreported:
+            msg, _FiniteGuard.unreported[:] = _FiniteGuard.unreported[0], []
+            raise RuntimeError(msg + " (found when an earlier renderer was collected: its last frames had not been examined)")
+        bad = False
+        while self.pending and ((wait and len(self.pending) > keep) or self.pending[0][0].query()):
+            ev, host = self.pending.pop(0)
+            ev.synchronize()
+            bad |= bool(int(host[0]) & 1)
+        if bad:
+            self.pending = []
+            self.status.zero_()
+            raise RuntimeError(self.message())
+
+    def after_launch(self, dev):
+        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        host.copy_(self.status, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        self.pending.append((ev, host))
+
+    def finalize(self):
+        """weakref.finalize of the renderer (garbage collection, or interpreter exit): the frames nobody examined.  An exception
+        cannot leave a finalizer, so: at interpreter exit the process ends with a non-zero status and the message on stderr; earlier,
+        the message is parked and raised by the next call of any renderer."""
+        import sys
+        if not self.pending:
+            return
+        try:
+            bad = False
+            for ev, host in self.pending:
+                ev.synchronize()
+                bad |= bool(int(host[0]) & 1)
+            self.pending = []
+        except Exception:      # the HIP runtime is already gone: nothing left to examine with
+            return
+        if bad:
+            if _EXITING[0]:
+                sys.stderr.write("RuntimeError: " + self.message() + " (found at interpreter exit: the last frames were never examined; "
+                                 "call renderer.check_finite() after the last forward())\n")
+                sys.stderr.flush()
+                import os
+                os._exit(70)
+            _FiniteGuard.unreported.append(self.message())
+
+
+_EXITING = [False]
+
+
+def _mark_exit():
+    _EXITING[0] = True
+
+
+import atexit  # noqa: E402
+# weakref.finalize callbacks run from an atexit hook registered when the FIRST finalize object is created; atexit runs hooks
+# last-in-first-out, so this one (registered at import, i.e. before any renderer exists ... but possibly after another module's
+# finalize) is re-registered by every renderer constructor to be sure it runs before them
+atexit.register(_mark_exit)
+
+
 def _f32c(t: torch.Tensor) -> torch.Tensor:
     return t.detach().to(torch.float32).contiguous()
 
@@ -123,12 +208,22 @@ class NeRFRendererDGS(torch.nn.Module):
         self._latent_gen = self._mlp_gen = 0         # bumped by every re-pack; the lin_z maps depend on both
         # Non-finite guard.  The compositing kernel ORs DINER_STATUS_NONFINITE into a device word when an rgb-sigma
         # sample is inf/NaN (in f16x3 mode: an MLP activation beyond the fp16 range, |x| >= ~1e6).  The word is copied
-        # to pinned host memory behind every call and examined WITHOUT a host sync: "deferred" (default) raises at the
-        # first later call (or check_finite()) that finds the copy complete; "sync" waits at the end of each call
-        # (render_image always does: once per frame); "off" never looks.
+        # to pinned host memory behind every call.  No frame can leave a program unexamined:
+        #   * a call that carries more than `finite_sync_rays` rays (anything larger than the reference's 4096-ray chunk:
+        #     a whole image / a large batch) or asks for the weights is examined before forward() returns (the wait is
+        #     microseconds against >= 30 ms of rendering); render_image always is;
+        #   * smaller chunks ("deferred"): forward() examines every copy that has completed and blocks only for frames
+        #     older than the two youngest -- the host never stalls the GPU, and at most two chunks are unexamined at any time;
+        #   * those last chunks are examined by check_finite(), by the next call of any renderer, and by a weakref.finalize of
+        #     this module: at garbage collection the finding is raised by the next call, at interpreter exit the process ends
+        #     with status 70 and the message on stderr (tests/test_gpu_edge.py).
+        # "sync" waits at the end of every call; "off" never looks.
         self.finite_check = "deferred"
-        self._status = None
-        self._pending = []                           # [(event, pinned host word)] oldest first
+        self.finite_sync_rays = 4096
+        self._guard = _FiniteGuard()
+        atexit.unregister(_mark_exit)
+        self._finalizer = weakref.finalize(self, self._guard.finalize)   # (registers weakref's own atexit hook the first time)
+        atexit.register(_mark_exit)                  # ... and this one after it: atexit is LIFO, so the flag is set before the finalizers run
 
     # ------------------------------------------------------------------------------------------
     # model -> packed device state (cached)
@@ -263,40 +358,21 @@ class NeRFRendererDGS(torch.nn.Module):
     def _status_word(self, dev) -> Optional[torch.Tensor]:
         if self.finite_check == "off":
             return None
-        if self._status is None or self._status.device != dev:
-            self._status = torch.zeros(1, dtype=torch.int32, device=dev)
-            self._pending = []
-        return self._status
+        return self._guard.word(dev)
 
-    def _poll_status(self, wait=False):
-        """Examine the completed status copies (all of them if ``wait``); raise if a frame went non-finite."""
-        bad = False
-        while self._pending and (wait or self._pending[0][0].query()):
-            ev, host = self._pending.pop(0)
-            if wait:
-                ev.synchronize()
-            bad |= bool(int(host[0]) & 1)
-        if bad:
-            self._pending = []
-            self._status.zero_()
-            raise RuntimeError(
-                "diner_amd.NeRFRendererDGS: a rendered rgb-sigma sample was inf/NaN" +
-                (" -- in precision='f16x3' an MLP activation left the fp16 range (|x| >= ~1e6, see DESIGN.md); set "
-                 "renderer.precision = 'fp32' (exact fp32 MFMA) for this model" if self.precision == "f16x3" else
-                 " -- the model itself produces non-finite values for these inputs"))
+    def _poll_status(self, wait=False, keep=0):
+        """Examine the completed status copies (all but the ``keep`` youngest if ``wait``); raise if a frame went non-finite."""
+        self._guard.precision = self.precision
+        self._guard.poll(wait=wait, keep=keep)
 
     def _after_launch(self, dev, sync=False):
-        if self._status is None or self.finite_check == "off":
+        if self._guard.status is None or self.finite_check == "off":
             return
-        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
-        host.copy_(self._status, non_blocking=True)
-        ev = torch.cuda.Event()
-        ev.record(torch.cuda.current_stream(dev))
-        self._pending.append((ev, host))
-        if len(self._pending) > 256:                 # never let the list grow without bound
+        self._guard.after_launch(dev)
+        if sync or self.finite_check == "sync":
             self._poll_status(wait=True)
-        elif sync or self.finite_check == "sync":
-            self._poll_status(wait=True)
+        else:
+            self._poll_status(wait=True, keep=2)     # never more than two small chunks unexamined; no stall: the GPU is two calls ahead
 
     def check_finite(self):
         """Wait for every render issued so far and raise ``RuntimeError`` if one produced inf/NaN samples."""
@@ -401,7 +477,7 @@ class NeRFRendererDGS(torch.nn.Module):
               "diner_render_points")
         return out
 
-    def composite(self, model, rays, z_samp, *, rgbsigma=None):
+    def composite(self, model, rays, z_samp, *, rgbsigma=None, _sync=False):
         """Alpha compositing (reference nerf_renderer.py:286-365) -> (weights, rgb, depth)."""
         r = self._check_rays(rays)
         z = _f32c(z_samp)
@@ -420,7 +496,7 @@ class NeRFRendererDGS(torch.nn.Module):
         self._poll_status()
         check(_lib.lib().diner_composite(_ptr(r), _ptr(z), _ptr(c), SB * NR, K, int(bool(self.white_bkgd)), _ptr(rgb),
                                          _ptr(depth), _ptr(weights), _ptr(self._status_word(dev)), _stream(dev)), "diner_composite")
-        self._after_launch(dev)
+        self._after_launch(dev, sync=_sync)
         return weights, rgb, depth
 
     @staticmethod
@@ -449,11 +525,9 @@ class NeRFRendererDGS(torch.nn.Module):
             SB, NR, _ = r.shape
             K = int(self.n_samples)
             dev = r.device
-            rgb = torch.empty((SB, NR, 3), dtype=torch.float32, device=dev)
-            depth = torch.empty((SB, NR), dtype=torch.float32, device=dev)
-            weights = torch.empty((SB, NR, K), dtype=torch.float32, device=dev) if want_weights else None
+            big = want_weights or SB * NR > int(self.finite_sync_rays)   # examined before this call returns (see __init__)
             if z_samples is not None:
-                w_, rgb, depth = self.composite(model, r, z_samples)
+                w_, rgb, depth = self.composite(model, r, z_samples, _sync=big)
                 weights = w_ if want_weights else None
             else:
                 packed = self._mlp(model)
@@ -464,11 +538,16 @@ class NeRFRendererDGS(torch.nn.Module):
                 if noise is not None:
                     u_c, n_g, u_f = [None if t is None else _f32c(t).to(dev) for t in noise]
                 prec = _lib.PRECISIONS[self.precision]
-                ws = torch.empty(int(_lib.lib().diner_render_workspace_floats(SB, NR, K, sc.NV, prec)), dtype=torch.float32, device=dev)
                 L, st, seed = _lib.lib(), _stream(dev), self._next_seed()
                 self._poll_status()
                 status = _ptr(self._status_word(dev))
-                if self.stage_events is None and noise is None and self.binding == "torch_ops":
+                use_ops = self.stage_events is None and noise is None and self.binding == "torch_ops"
+                if not use_ops:    # (the op allocates its own workspace and outputs: never both sets at once)
+                    ws = torch.empty(int(L.diner_render_workspace_floats(SB, NR, K, sc.NV, prec)), dtype=torch.float32, device=dev)
+                    rgb = torch.empty((SB, NR, 3), dtype=torch.float32, device=dev)
+                    depth = torch.empty((SB, NR), dtype=torch.float32, device=dev)
+                    weights = torch.empty((SB, NR, K), dtype=torch.float32, device=dev) if want_weights else None
+                if use_ops:
                     from . import ops as _ops
                     maps_t, poses_t, focal_t, c_t, latent_t, linz_t = _keep
                     rgb, depth, w_ = _ops.load().render(maps_t, poses_t, focal_t, c_t, latent_t, linz_t, packed, r, sc.image_w, sc.image_h,
@@ -495,7 +574,7 @@ class NeRFRendererDGS(torch.nn.Module):
                                             _ptr(depth), _ptr(weights), status, st), "diner_composite")
                     ev[3].record()
                     self.stage_events.append(ev)
-                self._after_launch(dev)
+                self._after_launch(dev, sync=big)
         return RenderOutput(fine=self._format_outputs(weights, rgb, depth, want_weights=want_weights))
 
     @torch.no_grad()
@@ -522,9 +601,6 @@ class NeRFRendererDGS(torch.nn.Module):
         cam.H, cam.W = int(H), int(W)
         prec = _lib.PRECISIONS[self.precision]
         L = _lib.lib()
-        ws = torch.empty(int(L.diner_render_image_workspace_floats(SB, int(H), int(W), K, sc.NV, prec)), dtype=torch.float32, device=dev)
-        rgb = torch.empty((SB, H * W, 3), dtype=torch.float32, device=dev)
-        depth = torch.empty((SB, H * W), dtype=torch.float32, device=dev)
         self._poll_status()
         seed = self._next_seed()
         if self.binding == "torch_ops":
@@ -535,6 +611,9 @@ class NeRFRendererDGS(torch.nn.Module):
                                                   cfg.n_gaussian, cfg.depth_diff_max, bool(self.white_bkgd), prec,
                                                   seed - (1 << 64) if seed >= (1 << 63) else seed, self._status_word(dev))
         else:
+            ws = torch.empty(int(L.diner_render_image_workspace_floats(SB, int(H), int(W), K, sc.NV, prec)), dtype=torch.float32, device=dev)
+            rgb = torch.empty((SB, H * W, 3), dtype=torch.float32, device=dev)
+            depth = torch.empty((SB, H * W), dtype=torch.float32, device=dev)
             check(L.diner_render_image(C.byref(sc), _ptr(packed), C.byref(cam), C.byref(cfg), int(bool(self.white_bkgd)), prec, seed,
                                        _ptr(ws), None, _ptr(rgb), _ptr(depth), None, _ptr(self._status_word(dev)), _stream(dev)), "diner_render_image")
         self._after_launch(dev, sync=self.finite_check != "off")    # once per frame: a NaN image never leaves this function

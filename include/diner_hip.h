@@ -93,6 +93,12 @@ typedef struct DinerTargetCam {
     int32_t H, W;            /* target image size: rays per scene = H*W, ray r = pixel (r / W, r % W) */
 } DinerTargetCam;
 
+/* Version of THIS ABI (argument lists, struct layouts).  Bumped by every incompatible change; a binding compiled or written
+ * against another value must refuse to call in: diner_version() returns the value the loaded library was built with, the
+ * torch-ops extension checks it at every op entry, diner_amd/_lib.py at load time.  (2: diner_render / diner_composite gained
+ * `status`.) */
+#define DINER_ABI_VERSION 2
+
 const char *diner_last_error(void);
 int diner_version(void);
 

@@ -84,6 +84,9 @@ def test_f16x3_envelope(ls, ws, bs):
             if finite_ref:
                 r.check_finite()
                 assert bool(torch.isfinite(o.fine.rgb).all())
+            else:            # fp32 overflows on this cell too: examined here, so that no unexamined frame outlives the test
+                with pytest.raises(RuntimeError, match="the model itself"):
+                    r.check_finite()
         # non-finite samples are NaN/inf, never finite garbage next to a finite oracle value
         bad = ~np.isfinite(f16).all(-1)
         if finite_ref and (~bad).any():
@@ -122,3 +125,78 @@ def test_nonfinite_is_raised_not_returned():
         m2 = model_from_scene(sc2, w2, device=dev)
         r(m2, T(rays2, dev))
         r.check_finite()
+
+
+# ---- the non-finite guard leaves no window -------------------------------------------------------------------
+_LAST_CALL_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from tests.test_gpu_magnitude import _case, T
+from diner_amd import NeRFRendererDGS
+from synthetic.model_stub import model_from_scene
+dev = torch.device("cuda:0")
+sc, w, rays = _case(%s, 1.0, 0.0)
+m = model_from_scene(sc, w, device=dev)
+r = NeRFRendererDGS(n_samples=16, n_depth_candidates=64, n_gaussian=4)
+assert rays.shape[1] <= r.finite_sync_rays      # a small chunk: the deferred path
+with torch.no_grad():
+    for i in range(3):
+        o = r(m, T(rays, dev))                  # the LAST call of the program; nobody calls check_finite()
+print("frames rendered", flush=True)
+"""
+
+
+@pytest.mark.parametrize("latent_scale,bad", [("1e7", True), ("1.0", False)])
+def test_last_call_of_a_program_is_examined(latent_scale, bad):
+    """forward() cannot end a program with an unexamined non-finite frame: a script whose LAST call is out of the f16x3 envelope
+    and which never calls check_finite() ends with a non-zero status and the RuntimeError text on stderr (weakref.finalize of the
+    renderer at interpreter exit); the same script inside the envelope exits 0."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = str(Path(__file__).resolve().parents[1])
+    p = subprocess.run([sys.executable, "-c", _LAST_CALL_SCRIPT % (root, latent_scale)], capture_output=True, text=True, timeout=600, cwd=root)
+    assert "frames rendered" in p.stdout, p.stderr[-2000:]
+    if bad:
+        assert p.returncode == 70 and "inf/NaN" in p.stderr and "precision = 'fp32'" in p.stderr, (p.returncode, p.stderr[-2000:])
+    else:
+        assert p.returncode == 0, p.stderr[-2000:]
+
+
+def test_nonfinite_window_is_closed_in_process():
+    from diner_amd import NeRFRendererDGS
+    from diner_amd.renderer import _FiniteGuard
+    from synthetic.model_stub import model_from_scene
+    import gc
+    dev = torch.device("cuda:0")
+    sc, w, rays = _case(1e7, 1.0, 0.0)
+    m = model_from_scene(sc, w, device=dev)
+    good_sc, good_w, good_rays = _case(1.0, 1.0, 0.0)
+    good = model_from_scene(good_sc, good_w, device=dev)
+    with torch.no_grad():
+        # (1) a call that carries more than the reference's 4096-ray chunk is examined before it returns
+        r = NeRFRendererDGS(n_samples=16, n_depth_candidates=64, n_gaussian=4)
+        big = T(np.repeat(rays, 4096 // rays.shape[1] + 1, axis=1), dev)
+        assert big.shape[1] > r.finite_sync_rays
+        with pytest.raises(RuntimeError, match="inf/NaN"):
+            r(m, big)
+        # (2) ... and so is one that returns the weights
+        with pytest.raises(RuntimeError, match="inf/NaN"):
+            r(m, T(rays, dev), want_weights=True)
+        # (3) small chunks: the host never waits for the chunk it has just issued, and never has more than two unexamined
+        r = NeRFRendererDGS(n_samples=16, n_depth_candidates=64, n_gaussian=4)
+        for i in range(6):
+            r(good, T(good_rays, dev))
+            assert len(r._guard.pending) <= 2
+        r.check_finite()
+        # (4) a renderer that is dropped with an unexamined bad chunk: the finding is raised by the next call of ANY renderer
+        r = NeRFRendererDGS(n_samples=16, n_depth_candidates=64, n_gaussian=4)
+        r(m, T(rays, dev))
+        del r
+        gc.collect()
+        r2 = NeRFRendererDGS(n_samples=16, n_depth_candidates=64, n_gaussian=4)
+        with pytest.raises(RuntimeError, match="earlier renderer was collected"):
+            r2(good, T(good_rays, dev))
+        assert not _FiniteGuard.unreported
+        r2(good, T(good_rays, dev))
+        r2.check_finite()

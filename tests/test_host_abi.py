@@ -25,7 +25,9 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/diner_hip.h but not exported"
     assert sorted(_lib.SYMBOLS) == names, "ctypes table and header drifted apart"
-    assert lib.diner_version() == 2
+    # one ABI version in three places: the header's define, what the library was built with, what the ctypes table is written for
+    header = (ROOT / "include" / "diner_hip.h").read_text()
+    assert lib.diner_version() == _lib.ABI_VERSION == int(re.search(r"#define DINER_ABI_VERSION (\d+)", header).group(1))
     fp32_img = 16 * 7 * 256 + 13 * 16 * 64 * 256 + 64 * 256 + 14 * 512 + 32
     f16_img = (16 * 4 * 1024 + 13 * 16 * 32 * 1024) // 2 + 14 * 512 + 32 + 4 * 512   # halfs of 14 layers | biases | lin_out weights (fp32: VALU head)
     assert lib.diner_mlp_packed_floats() == fp32_img + f16_img

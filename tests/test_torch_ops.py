@@ -14,10 +14,32 @@ def test_extension_builds_and_registers():
         schema = str(getattr(o, name).default._schema)
         assert schema.startswith(f"diner::{name}(Tensor maps, Tensor poses"), schema
     assert "Tensor? status" in str(o.render.default._schema)
+    from diner_amd import _lib
+    assert int(o.abi_version()) == _lib.lib().diner_version() == _lib.ABI_VERSION
     # no CPU kernel is registered: host tensors are refused by the dispatcher, not silently computed elsewhere
     t = torch.zeros(1)
     with pytest.raises((NotImplementedError, RuntimeError)):
         o.render(t, t, t, t, t, None, t, t, 1.0, 1.0, 0.0, 6, 1.0, 8, 4, 1, 0.05, True, 1, 0, False, None)
+
+
+def test_stale_extension_is_not_used(tmp_path, monkeypatch):
+    """an extension built against another libdiner_hip.so / torch_ops.cpp / header may carry another argument list.
+    It is recognised by content (the stamp written by build()), not taken as a binding, and load() refuses it."""
+    from diner_amd import ops
+    ops.build()
+    assert ops.available() and not ops.stale()
+    good = ops.STAMP.read_text()
+    try:
+        ops.STAMP.write_text("0" * 64 + "\n")       # = built from other sources
+        assert ops.stale() and not ops.available()
+        import diner_amd
+        assert diner_amd.NeRFRendererDGS().binding == "ctypes"
+        monkeypatch.setattr(ops, "_loaded", False)
+        with pytest.raises(RuntimeError, match="rebuild"):
+            ops.load()
+    finally:
+        ops.STAMP.write_text(good)
+    assert ops.available()
 
 
 @pytest.mark.gpu
