@@ -165,6 +165,29 @@ def kernel_source_digest() -> str:
     return h.hexdigest()[:16]
 
 
+SMALL_KERNEL_SOURCES = ("sampler.hip", "composite.hip", "common.hpp", "Makefile")
+
+
+def small_kernel_source_digest() -> str:
+    """the same for sampler_kernel / composite_kernel (the `sampling_integration` object)"""
+    h = hashlib.sha256()
+    for name in SMALL_KERNEL_SOURCES:
+        h.update((ROOT / "diner_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()[:16]
+
+
+def small_traffic_record(args):
+    """measured L2-miss bytes per launch of the sampler and the compositing kernel + the sampler's VALU-busy fraction, recorded by
+    tools/pmc_summary.py from the PMC passes of this command; None when never recorded or the two kernels changed since"""
+    p = ROOT / "profiles" / "traffic.json"
+    if not p.exists():
+        return None
+    rec = json.loads(p.read_text()).get(f"{args.config}:{args.precision}:{args.rays_per_call}:sampling_integration")
+    if not isinstance(rec, dict) or rec.get("kernel_src_sha16") != small_kernel_source_digest():
+        return None
+    return rec
+
+
 def traffic_record(args):
     """HBM bytes per launch of the dominant kernel: PMC counters cannot be read from inside the run (rocprofv3 collects them
     in separate passes), so this is the figure tools/pmc_summary.py recorded in profiles/traffic.json from such passes of this
@@ -179,6 +202,37 @@ def traffic_record(args):
     if rec.get("kernel_src_sha16") != kernel_source_digest():
         return None, f"stale: {rec.get('source')} was taken with kernel sources {rec.get('kernel_src_sha16')}"
     return rec["bytes_per_launch"], rec.get("source")
+
+
+def sampling_integration(args, b_s, b_c, rays_per_launch, t_samp, t_comp):
+    """The north_star's ">= 40 % HBM roofline on the sampling + integration kernel" clause, stated honestly: `frac` is on SURVEY
+    8(d)'s LOGICAL bytes (every map / tensor element counted once per access), as that clause defines it; next to it what the
+    hardware moved (`traffic` = PMC L2-miss bytes of the two kernels, `frac_measured`) and what really bounds each kernel: the
+    sampler is VALU-bound (its 33 MB of maps are cache-served), only the compositing kernel streams from HBM."""
+    si_gbs = (b_s + b_c) * rays_per_launch / ((t_samp + t_comp) * 1e-3) / 1e9
+    out = {"kernels": "sampler_kernel + composite_kernel", "bound": "hbm (logical bytes, SURVEY 8(d)); see `per_kernel` for the real bounds",
+           "achieved": si_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": si_gbs / PEAK_HBM_GBS,
+           "logical_bytes_per_ray": b_s + b_c, "avg_ms": [t_samp, t_comp], "traffic": None, "frac_measured": None,
+           "per_kernel": {
+               "sampler_kernel": {"bound": "valu", "logical_gbs": b_s * rays_per_launch / (t_samp * 1e-3) / 1e9, "avg_ms": t_samp},
+               "composite_kernel": {"bound": "hbm", "logical_gbs": b_c * rays_per_launch / (t_comp * 1e-3) / 1e9, "avg_ms": t_comp,
+                                    "frac": b_c * rays_per_launch / (t_comp * 1e-3) / 1e9 / PEAK_HBM_GBS}}}
+    rec = small_traffic_record(args)
+    if rec is None:
+        out["traffic_source"] = "no PMC pass recorded for these kernel sources"
+        return out
+    tr = {k: rec[k]["bytes_per_launch"] for k in ("sampler", "composite") if k in rec}
+    out["traffic"] = sum(tr.values())
+    out["traffic_source"] = rec.get("source")
+    out["frac_measured"] = out["traffic"] / ((t_samp + t_comp) * 1e-3) / 1e9 / PEAK_HBM_GBS
+    pk = out["per_kernel"]
+    if "sampler" in rec:
+        pk["sampler_kernel"].update(traffic=tr["sampler"], measured_gbs=tr["sampler"] / (t_samp * 1e-3) / 1e9,
+                                    valu_busy_frac=rec["sampler"].get("valu_busy_frac"))
+    if "composite" in rec:
+        pk["composite_kernel"].update(traffic=tr["composite"], measured_gbs=tr["composite"] / (t_comp * 1e-3) / 1e9,
+                                      frac_measured=tr["composite"] / (t_comp * 1e-3) / 1e9 / PEAK_HBM_GBS)
+    return out
 
 
 def stub_tile(rays):
@@ -400,7 +454,6 @@ def main(argv=None):
         f_exec = K * 2 * macs * rays_per_launch * MFMA_PASSES[args.precision]
         peak = PEAK_MFMA_TFLOPS[args.precision]
         b_s, b_c = 32 + NC * NV * 20 + 4 * K, K * 20 + 32 + 16  # logical bytes/ray
-        si_gbs = (b_s + b_c) * rays_per_launch / ((t_samp + t_comp) * 1e-3) / 1e9
         traffic, traffic_source = traffic_record(args)
         result["roofline"] = {
             "kernel": "points_mlp_kernel" if args.precision == "fp32" else "points_mlp_f16_kernel",
@@ -413,11 +466,7 @@ def main(argv=None):
             "note": "achieved = algorithmic FLOP of the reference MLP / kernel time; executed = MFMA FLOP actually "
                     "issued (x3 passes in f16x3 mode, minus the layers hoisted out of the per-point path); traffic = L2-miss "
                     "bytes (HBM + Infinity Cache) of a recorded PMC pass of this command, null when the kernel changed since",
-            "sampling_integration": {"kernels": "sampler_kernel + composite_kernel", "bound": "latency/VALU (maps are cache-served); "
-                                     "fraction quoted on SURVEY §8(d)'s logical bytes",
-                                     "achieved": si_gbs, "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                     "frac": si_gbs / PEAK_HBM_GBS, "logical_bytes_per_ray": b_s + b_c,
-                                     "avg_ms": [t_samp, t_comp]}}
+            "sampling_integration": sampling_integration(args, b_s, b_c, rays_per_launch, t_samp, t_comp)}
     else:
         result["roofline"] = None
         result["stub_frame_ok"] = stub_ok

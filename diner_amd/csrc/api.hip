@@ -3,6 +3,8 @@
 #include <stdarg.h>
 #include <stdio.h>
 
+#include <atomic>
+
 #include "common.hpp"
 
 namespace diner {
@@ -24,6 +26,44 @@ int check_launch(const char *what)
         set_error("%s: %s", what, hipGetErrorString(e));
         return DINER_E_LAUNCH;
     }
+    return DINER_OK;
+}
+
+// ---- per-device launch state (common.hpp) ---------------------------------------------------------------------------------------
+constexpr int MAX_DEVICES = 64;
+static std::atomic<int> g_cus[MAX_DEVICES];                       // 0 = not asked yet
+static std::atomic<int> g_lds_set[MAX_DEVICES][LDS_SLOT_COUNT];   // bytes the kernel of a slot has been raised to on a device
+
+static int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); dev = 0; }
+    return dev;
+}
+
+int device_cus()
+{
+    const int dev = current_device();
+    if (dev < 0 || dev >= MAX_DEVICES) {      // beyond the table: ask every time
+        int n = 0;
+        return (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0) ? n : 256;
+    }
+    int n = g_cus[dev].load(std::memory_order_relaxed);
+    if (!n) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) { (void)hipGetLastError(); n = 256; }
+        g_cus[dev].store(n, std::memory_order_relaxed);
+    }
+    return n;
+}
+
+int ensure_dynamic_lds(const void *kernel, int bytes, int slot)
+{
+    const int dev = current_device();
+    const bool cached = dev >= 0 && dev < MAX_DEVICES && slot >= 0 && slot < LDS_SLOT_COUNT;
+    if (cached && g_lds_set[dev][slot].load(std::memory_order_acquire) == bytes) return DINER_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess)
+        return check_launch("hipFuncSetAttribute(dynamic LDS)");
+    if (cached) g_lds_set[dev][slot].store(bytes, std::memory_order_release);
     return DINER_OK;
 }
 

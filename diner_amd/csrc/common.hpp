@@ -18,6 +18,13 @@ namespace diner {
 void set_error(const char *fmt, ...);
 int check_launch(const char *what);
 
+// Launch state that belongs to the DEVICE, not the process (a process may render on cuda:1 after cuda:0): the CU count that sizes the
+// persistent grids, and the raised dynamic-LDS limit of a kernel (hipFuncSetAttribute acts on the current device's copy of the function).
+// Both are cached per device ordinal (api.hip); thread-safe (atomics; a race only repeats an idempotent call).
+int device_cus();                                                    // CUs of the current device (256 on MI355X)
+enum LdsSlot { LDS_SLOT_F16_LINZ, LDS_SLOT_F16_LATENT, LDS_SLOT_F16_TRACE, LDS_SLOT_TRAIN_CORE0, LDS_SLOT_COUNT = LDS_SLOT_TRAIN_CORE0 + 4 };
+int ensure_dynamic_lds(const void *kernel, int bytes, int slot);    // DINER_OK, or DINER_E_LAUNCH with the error set
+
 // --------------------------------------------------------------------------------------------
 // camera of one source view, held in registers (SGPRs once the compiler sees it is uniform)
 // --------------------------------------------------------------------------------------------

@@ -48,6 +48,7 @@ WBITS = ""                                      # --wbits=nt|sc0|...: cache-poli
 STAMPS = False                                  # --stamps: diagnostic layer blocks only (namespace of --ns), 6 s_memtime stamps each (tools/trace_f16.py)
 FLOW = False                                    # --flow: arrival counters in LDS instead of the three workgroup barriers per layer
 X_OFF, NET_OFF, RING_OFF = 0, 64, 128           # relative to CAP
+POISON_OFF = 24                                 # byte offset (from the arrival counters) of the workgroup's poison word, see Block.wait
 
 
 def acc(base, tn, tp):
@@ -143,8 +144,14 @@ class Block:
         self.e(f"s_cbranch_scc1 T{lbl}")
         self.e("s_sleep 1")
         self.e(f"s_branch {lbl}")
-        self.e(f"T{lbl}:")                                             # timed out: poison this wave's x grid -> every sample of the tile comes out
-        self.e(f"v_mov_b32 v{CAP + X_OFF}, 0x7fc00000")               # NaN -> the compositing kernel raises DINER_STATUS_NONFINITE (loud, no hang)
+        # timed out (a protocol error; unreachable in a correct build): the wave goes on with operand rows nobody vouches for, so the
+        # WHOLE tile must come out non-finite, not just this wave's share: set the workgroup's poison word (LDS, %[ctr] + POISON_OFF;
+        # never cleared).  The kernels read it where their results leave: the point kernel's head writes NaN for every sample of the
+        # tile (-> DINER_STATUS_NONFINITE), the training core's epilogue writes NaN into C and inf into amax_out.  Loud, no hang.
+        self.e(f"T{lbl}:")
+        self.e(f"v_mov_b32 v{CAP + X_OFF}, 0x7fc00000")
+        self.e("v_mov_b32 %[pv], 1")
+        self.e(f"ds_write_b32 %[ctr], %[pv] offset:{POISON_OFF}")
         self.e(f"{done}:")
 
     def body(self, tail, switch):
@@ -247,10 +254,15 @@ class Block16(Block):
     Weight stream of a wave: ONE sequence of half-steps, 4 KiB each: [tf2][hi/lo][lane][8 halfs], lane = 16 kq + r holds
     W[feature 16 (2j + tf2) + r][k = 32 kstep + 8 kq ..+7].  nkb1 / nkb2 count k-steps."""
 
-    def __init__(self, name, acc_base, nks1, nks2, D, region1_off=65536):
+    def __init__(self, name, acc_base, nks1, nks2, D, region1_off=65536, zero_init=False):
         assert D == 2 and nks1 > 0
         self.name, self.base, self.nkb1, self.nkb2, self.D = name, acc_base, nks1, nks2, D
         self.region1_off = region1_off
+        # zero_init: the accumulators need no initialisation by the caller -- the first product of every accumulator takes the inline
+        # constant 0 as its C operand (D = A*B + 0).  Only for blocks whose first half is ONE k-step (lin_in), where "first" is static.
+        self.zero_init = zero_init
+        assert not zero_init or nks1 == 1
+        self.first_step = False
         self.lines = []
         self.nlabel = 0
 
@@ -281,7 +293,8 @@ class Block16(Block):
         pairs = [(p, tf2) for tf2 in range(2) for p in prods] if ORDER == "acc" else [(p, tf2) for p in prods for tf2 in range(2)]
         for (wpart, fpart), tf2 in pairs:                             # --order=acc: the 3 products of an accumulator back to back
             a = self.acc16(2 * j + tf2, tp)
-            self.e(f"v_mfma_f32_16x16x32_f16 {a}, {ring(j, tf2, wpart)}, {self.fr(tp, fpart)}, {a}")
+            c = "0" if self.first_step and (wpart, fpart) == prods[0] else a     # zero_init: the accumulator's first product of the layer
+            self.e(f"v_mfma_f32_16x16x32_f16 {a}, {ring(j, tf2, wpart)}, {self.fr(tp, fpart)}, {c}")
 
     def body(self, tail, switch):
         for j in range(2):
@@ -302,6 +315,7 @@ class Block16(Block):
         self.e(f"v_add_u32 %[ab], {self.region1_off * region}, %[ab0]")
         for tp in range(4):
             self.frag_read(tp)                                        # the half's first k-step, behind the barrier / arrival wait
+        self.first_step = self.zero_init and region == 0              # (nks == 1 there: the tail body below is the layer's first k-step)
         if nks > 1:
             lbl = f"L{self.nlabel}_%="
             self.nlabel += 1
@@ -312,6 +326,7 @@ class Block16(Block):
             self.e("s_cmp_lg_u32 %[cnt], 0")
             self.e(f"s_cbranch_scc1 {lbl}")
         self.body(tail=True, switch=last_half)
+        self.first_step = False
 
 
 def clobbers(D):
@@ -491,6 +506,7 @@ def sync_struct():
 // synchronisation state a layer block takes: barrier mode needs none of it; flow mode ({'ON' if FLOW else 'off'} in this build):
 // ctr = LDS address of the four arrival counters (SA, SB, G1, G2), ctrh = ctr + 4 * (wave >= 4), one = 1, lay = number of the layer, half = (wave >= 4)
 constexpr bool F16_FLOW = {'true' if FLOW else 'false'};
+constexpr int F16_POISON_OFF = {POISON_OFF};   // byte offset of the poison word behind the counters: set by a wait that gave up (never in a correct build)
 struct Sync {{ unsigned ctr, ctrh, one, lay, half; }};
 // one lane adds 1 to the LDS counter at `addr` (after this wave's LDS operations have completed)
 __device__ __forceinline__ void flow_signal(unsigned addr, unsigned one)
@@ -561,6 +577,8 @@ def main():
         out.append(cxx(B_("layer_x_full", X_OFF, NK, NK, D)))
         out.append(cxx(B_("layer_net_full", NET_OFF, NK, NK, D)))
         out.append(cxx(B_("layer_x_in", X_OFF, NKI, NKI, D, region1_off=8192)))
+        if SHAPE == 16:
+            out.append(cxx(B_("layer_x_in0", X_OFF, NKI, NKI, D, region1_off=8192, zero_init=True)))
         out.append("}  // namespace " + ns + "\n")
         sys.stdout.write("\n".join(out))
         return
@@ -579,6 +597,8 @@ constexpr int F16_X = {CAP + X_OFF}, F16_NET = {CAP + NET_OFF};   // first regis
     # lin_in: 64 inputs = 4 k-blocks; waves 0-3 write unit-rows 0-3 (k < 32), waves 4-7 unit-rows 4-7 (8 KiB further)
     if D == 2:   # (the ring-4 build is a probe-only variant: tools/chain_probe.hip)
         out.append(cxx(B_("layer_x_in", X_OFF, NKI, NKI, D, region1_off=8192)))
+        if SHAPE == 16:   # x := W_in * in (no bias init by the caller: lin_in's bias travels in the lin_z[0] map)
+            out.append(cxx(B_("layer_x_in0", X_OFF, NKI, NKI, D, region1_off=8192, zero_init=True)))
     out.append(gather_cxx(D))
     if ns:
         out.append("}  // namespace " + ns + "\n")

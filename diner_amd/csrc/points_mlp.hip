@@ -352,7 +352,11 @@ __global__ __launch_bounds__(NWAVES * 64) void points_mlp_kernel(DinerScene s, c
 // up to fp32 rounding.  Evaluating lin_z on the latent MAP once per encode (NV*h*w rows instead of
 // NV * points rows per frame: 0.64 TFLOP instead of 211 TFLOP at the headline config) removes three of
 // the nine per-view GEMMs from the per-point kernel, which then adds bilerp(G_b) straight into its
-// accumulators.  Exact fp32 MFMA here (bit-identical to an fmaf chain), bias included.
+// accumulators.  Exact fp32 MFMA here (bit-identical to an fmaf chain), bias included -- and with it the bias the residual stream
+// receives at the same place (the bilinear weights of a point sum to 1, so a constant of the map arrives as that constant):
+//   map 0 also carries lin_in's bias      (x = lin_in(in) + b_in;  x += lin_z[0](z)        resnetfc.py:139,152),
+//   map b >= 1 also carries fc_1[b-1]'s   (x = x + fc_1(...) + b1; x += lin_z[b](z)        resnetfc.py:69,152),
+// so the per-point kernel adds three bias vectors per view fewer (points_mlp_f16.hip, LINZ path).
 // in: latent [N,h,w,512] NHWC rows; out: [3][N,h,w,512].
 __global__ __launch_bounds__(NWAVES * 64) void linz_maps_kernel(const float *__restrict__ latent, int64_t rows,
                                                                 const float *__restrict__ Wp, float *__restrict__ out)
@@ -380,6 +384,7 @@ __global__ __launch_bounds__(NWAVES * 64) void linz_maps_kernel(const float *__r
     for (int b = 0; b < DINER_COMBINE_LAYER; ++b) {
         f32x16 acc[2][CT];
         acc_set_bias(acc, bias + 512 * bias_slot_lin_z(b), wave, lane);
+        acc_add_bias(acc, bias + 512 * (b == 0 ? bias_slot_lin_in() : bias_slot_fc1(b - 1)), wave, lane);
         gemm_tile<NJB_FULL>(acc, A4, (const f32x4 *)(Wp + OFF_LIN_Z + b * W_FULL), wave, lane);
         float *dst = out + (int64_t)b * rows * HID;
         const int c = lane & 31, h = lane >> 5;

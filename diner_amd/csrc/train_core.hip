@@ -238,6 +238,10 @@ __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_num_vgpr(F16_VGP
                 *(f32x4 *)(stage + row * 256 + ((q4 ^ (row & 15)) << 4)) = v;
             });
             const int rq = lane >> 4, q4 = lane & 15, col = wave * 64 + 4 * q4;
+            // the core's poison word (a flow wait that gave up: never in a correct build): the tile's C becomes NaN, amax_out inf -- a
+            // silently wrong gradient is the one thing this kernel must not produce
+            const bool poisoned = F16_FLOW && *(volatile unsigned *)(lds + LDS_CTR + F16_POISON_OFF) != 0;
+            if (poisoned) amax = __builtin_inff();
 #pragma unroll 1
             for (int i0 = 0; i0 < 16; i0 += 4) {
                 f32x4 msk[4], old[4];
@@ -260,6 +264,7 @@ __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_num_vgpr(F16_VGP
                         float t = v[q] * unscale + bias4[q];
                         if (HAS_S) t = msk[i][q] > 0.0f ? t : 0.0f;
                         if (HAS_ADD) t = old[i][q] + t;
+                        if (poisoned) t = __builtin_nanf("");
                         v[q] = t;
                         if (ok) {
                             cs[q] += t;
@@ -308,19 +313,9 @@ int launch_train_gemm_core(const float *A, int64_t sam, const void *Wcore, const
     if (M == 0) return DINER_OK;
     const void *fn = S ? (addend ? (const void *)train::core::gemm_core_kernel<true, true> : (const void *)train::core::gemm_core_kernel<true, false>)
                        : (addend ? (const void *)train::core::gemm_core_kernel<false, true> : (const void *)train::core::gemm_core_kernel<false, false>);
-    static bool attr_set[4] = {false, false, false, false};
     const int which = (S ? 2 : 0) + (addend ? 1 : 0);
-    if (!attr_set[which]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, train::core::LDS_BYTES) != hipSuccess)
-            return check_launch("hipFuncSetAttribute(dynamic LDS)");
-        attr_set[which] = true;
-    }
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0, n = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-        cus = n;
-    }
+    if (const int rc = ensure_dynamic_lds(fn, train::core::LDS_BYTES, LDS_SLOT_TRAIN_CORE0 + which)) return rc;   // per device (common.hpp)
+    const int cus = device_cus();
     const int64_t tiles = (M + train::core::TILE_M - 1) / train::core::TILE_M;
     const unsigned grid = (unsigned)(tiles < cus ? tiles : cus);
     train::core::Args g{A, sam, (const _Float16 *)Wcore, bias, S, addend, C, M, ldc, lds, ldadd, relu_a, amax_a, exp_a, exp_b, colsum, amax_out};

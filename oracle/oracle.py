@@ -51,7 +51,8 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        _lib = C.CDLL(str(build()))
+        # DINER_ORACLE_SO: another build of the same file, e.g. the sanitizer build of `make -C oracle asan-test`
+        _lib = C.CDLL(os.environ.get("DINER_ORACLE_SO") or str(build()))
         _lib.orc_mlp_prepare.restype = C.c_void_p
     return _lib
 

@@ -267,3 +267,31 @@ def test_linz_maps_budget_and_memory_report(dev):
         assert rep["cached"]["total"] == sum(v for k, v in rep["cached"].items() if k != "total")
         assert rep["per_call"]["workspace"] > 0 and rep["training_step"]["saved_activations"] > 0
     np.testing.assert_allclose(outs[0], outs[1], rtol=0, atol=1e-4)
+
+
+def test_second_device_uses_its_own_launch_state():
+    """the raised dynamic-LDS limit of a kernel and the CU count that sizes the persistent grids belong to the
+    DEVICE (diner_amd/csrc/api.hip: device_cus / ensure_dynamic_lds, cached per device ordinal), not to the process: a process that
+    renders on cuda:1 after cuda:0 must get the same frame there.  Needs two visible GPUs (the 1-GPU boxes skip it)."""
+    if torch.cuda.device_count() < 2:
+        pytest.skip("only one GPU visible")
+    from diner_amd import NeRFRendererDGS
+    from synthetic.model_stub import model_from_scene
+    sc, w = make(seed=3)
+    rays = sc.target_rays()[:, ::5]
+    K, NC, G = 24, 300, 8
+    noise = synth.make_noise(rays.shape[1], NC, G, K, seed=1)
+    outs = []
+    for d in (0, 1, 0):
+        dv = torch.device("cuda", d)
+        with torch.cuda.device(dv):
+            m = model_from_scene(sc, w, device=dv)
+            for prec in ("f16x3", "fp32"):
+                r = NeRFRendererDGS(n_samples=K, n_depth_candidates=NC, n_gaussian=G, white_bkgd=sc.white_bkgd)
+                r.precision = prec
+                with torch.no_grad():
+                    o = r(m, T(rays, dv), want_weights=True, noise=tuple(T(n, dv) for n in noise))
+                outs.append((d, prec, o.fine.rgb.cpu(), o.fine.depth.cpu()))
+    for d, prec, rgb, depth in outs[2:]:
+        ref = next(o for o in outs if o[1] == prec)
+        assert torch.equal(rgb, ref[2]) and torch.equal(depth, ref[3]), (d, prec)

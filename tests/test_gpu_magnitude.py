@@ -35,11 +35,43 @@ def _case(ls, ws, bs):
 @pytest.mark.parametrize("ws", WEIGHT)
 @pytest.mark.parametrize("ls", LATENT)
 def test_f16x3_envelope(ls, ws, bs):
+    sc, w, rays = _case(ls, ws, bs)
+    _fp32_grade_or_loud(sc, w, rays, f"latent x{ls:g} weights x{ws:g} bias {bs:g}")
+
+
+def _cnn_case(gain, seed=11):
+    """Statistics a trained ResNet34 trunk + MLP actually has, unlike the unit-scale gaussians above: the
+    latent is POST-ReLU (non-negative, ~half of it exactly 0), HEAVY-TAILED (half-Student-t, 3 degrees of freedom: outliers of
+    30-100 sigma) with PER-CHANNEL scales spread log-uniformly over 1e-3 ... 1e2; every weight matrix has its output rows scaled
+    log-uniformly over a factor 10 (row norms of trained layers are far from equal).  `gain` scales the whole latent."""
+    sc, w, rays = _case(1.0, 1.0, 1.0)
+    rs = np.random.RandomState(seed)
+    shape = sc.latent.shape                                   # [1, NV, C, h, w]
+    t = rs.standard_t(3, size=shape).astype(np.float32)
+    ch = np.exp(rs.uniform(np.log(1e-3), np.log(1e2), size=(1, 1, shape[2], 1, 1))).astype(np.float32)
+    sc.latent = np.ascontiguousarray(np.maximum(t, 0.0) * ch * np.float32(gain))
+    out = {}
+    for k, v in w.items():
+        if k.endswith("weight") and v.ndim == 2:
+            rows = np.exp(rs.uniform(-0.5 * np.log(10.0), 0.5 * np.log(10.0), size=(v.shape[0], 1))).astype(np.float32)
+            v = (v * rows).astype(np.float32)
+        out[k] = v
+    return sc, out, rays    # (at gain 1 the latent has std 25 and outliers beyond 2000: the three gains span std 0.75 ... 750)
+
+
+@pytest.mark.parametrize("gain", [0.03, 1.0, 30.0])
+def test_f16x3_envelope_cnn_statistics(gain):
+    sc, w, rays = _cnn_case(gain)
+    lat = sc.latent
+    assert float(lat.min()) >= 0.0 and 0.3 < float((lat == 0).mean()) < 0.7 and float(lat.max()) > 50 * float(lat.std())
+    _fp32_grade_or_loud(sc, w, rays, f"CNN-like latent (post-ReLU, heavy-tailed, channel scales 1e-3..1e2) x{gain:g}, weight rows x10 spread")
+
+
+def _fp32_grade_or_loud(sc, w, rays, label):
     from diner_amd import NeRFRendererDGS
     from synthetic.model_stub import model_from_scene
     from oracle.oracle import Oracle
     dev = torch.device("cuda:0")
-    sc, w, rays = _case(ls, ws, bs)
     K = 16
     m = model_from_scene(sc, w, device=dev)
     z = np.sort(np.random.RandomState(1).uniform(sc.near, sc.far, (1, rays.shape[1], K)).astype(np.float32), -1)
@@ -93,7 +125,7 @@ def test_f16x3_envelope(ls, ws, bs):
             e = np.abs(f16 - ref)[~bad]
             assert float(e.max()) <= max(1e-3, 30 * float(e32.max())), "finite garbage next to non-finite samples"
         verdict = f"LOUD ({bad.mean():.0%} of the samples non-finite)"
-    print(f"latent x{ls:g} weights x{ws:g} bias {bs:g}: sigma max {np.nanmax(ref[..., 3]):.3g} -> f16x3 {verdict}")
+    print(f"{label}: sigma max {np.nanmax(ref[..., 3]):.3g} -> f16x3 {verdict}")
 
 
 def test_nonfinite_is_raised_not_returned():

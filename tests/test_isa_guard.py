@@ -16,15 +16,21 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 CSRC = ROOT / "diner_amd" / "csrc"
 
 
-@pytest.fixture(scope="module")
-def isa(tmp_path_factory):
+def _compile(tmp_path_factory, *defines):
     if not Path(HIPCC).exists():
         pytest.skip("hipcc not available")
     subprocess.run(["make", "-C", str(CSRC), "f16_core.inc", "f16_core16.inc", "f16_core16_trace.inc"], check=True, capture_output=True)
     asm = tmp_path_factory.mktemp("isa") / "points_mlp_f16.s"
     subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fno-unroll-loops", "-Wno-inline-asm", "-S",
-                    "--cuda-device-only", "-o", str(asm), str(CSRC / "points_mlp_f16.hip")], check=True, capture_output=True, timeout=900)
+                    "--cuda-device-only", *defines, "-o", str(asm), str(CSRC / "points_mlp_f16.hip")], check=True, capture_output=True, timeout=900)
     return asm.read_text()
+
+
+@pytest.fixture(scope="module", params=["product", "diag"])
+def isa(request, tmp_path_factory):
+    """the product build (2 instantiations) and the tools build with the TRACE instantiation (-DDINER_F16_DIAG: 3)"""
+    text = _compile(tmp_path_factory, *(["-DDINER_F16_DIAG"] if request.param == "diag" else []))
+    return text, (3 if request.param == "diag" else 2)
 
 
 def _cap():
@@ -49,10 +55,11 @@ def test_generated_core_is_current():
 
 
 def test_compiler_stays_out_of_the_core_registers(isa):
+    isa, n_inst = isa
     cap = _cap()
     lines = isa.split("\n")
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN5diner5f16x321points_mlp_f16_kernelILb[01]ELb[01]E\S+:", l)]
-    assert len(starts) == 3, "expected the instantiations <lin_z maps>, <per-point lin_z GEMMs> and the diagnostic <trace> build"
+    assert len(starts) == n_inst, "expected the instantiations <lin_z maps>, <per-point lin_z GEMMs> (+ the <trace> one in the tools build)"
     for s0 in starts:
         end = next(i for i in range(s0, len(lines)) if "s_endpgm" in lines[i])
         in_asm, core_mfma, core_loads, stmt = False, 0, 0, []
@@ -81,8 +88,37 @@ def test_compiler_stays_out_of_the_core_registers(isa):
 
 def test_register_budget(isa):
     """2 waves per SIMD: 256 registers per lane in all, none of them AGPRs."""
+    isa, n_inst = isa
     meta = re.findall(r"\.agpr_count:\s+(\d+)\n\s+\.args:.*?\.name:\s+(\S+).*?\.vgpr_count:\s+(\d+)", isa, flags=re.S)
     kern = [(int(a), n, int(v)) for a, n, v in meta if "points_mlp_f16_kernel" in n]
-    assert len(kern) == 3
+    assert len(kern) == n_inst
     for agpr, name, vgpr in kern:
         assert agpr == 0 and vgpr <= 256, (name, agpr, vgpr)
+
+
+def test_product_library_carries_no_diagnostics():
+    """the TRACE instantiation, its getenv / hipMalloc / fprintf live in the tools build only
+    (tools/dbg/build_abl.sh trace -DDINER_F16_DIAG), not in libdiner_hip.so."""
+    so = ROOT / "diner_amd" / "lib" / "libdiner_hip.so"
+    if not so.exists():
+        pytest.skip("library not built")
+    blob = so.read_bytes()
+    assert b"DINER_F16_TRACE" not in blob and b"[f16 trace]" not in blob
+    assert b"points_mlp_f16_kernelILb1ELb1E" not in blob          # <LINZ, TRACE = true>
+    assert b"points_mlp_f16_kernelILb1ELb0E" in blob and b"points_mlp_f16_kernelILb0ELb0E" in blob
+
+
+def test_a_wait_that_gives_up_poisons_the_whole_tile():
+    """the bounded spin of a flow-mode wait must end LOUD for the whole tile, not for one register of one wave: the
+    generated timeout path sets the workgroup's poison word, and both kernels built on the core turn it into non-finite results."""
+    for name in ("f16_core16.inc", "f16_core.inc", "f16_core16_trace.inc"):
+        text = (CSRC / name).read_text()
+        off = int(re.search(r"constexpr int F16_POISON_OFF = (\d+);", (CSRC / "f16_core16.inc").read_text()).group(1))
+        waits = re.findall(r'"TW\d+_%=:\\n"\n(.*?)"D\d+_%=:\\n"', text, flags=re.S)
+        assert len(waits) >= 9, name                                    # 3-4 waits per layer block, 3 blocks
+        for w in waits:
+            assert f"ds_write_b32 %[ctr], %[pv] offset:{off}" in w and "v_mov_b32 %[pv], 1" in w, name
+    for src, what in (("points_mlp_f16.hip", "__builtin_nanf"), ("train_core.hip", "__builtin_nanf")):
+        text = (CSRC / src).read_text()
+        assert "LDS_CTR + F16_POISON_OFF" in text and what in text, src
+    assert "amax = __builtin_inff()" in (CSRC / "train_core.hip").read_text()

@@ -26,7 +26,7 @@ def short(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("config")
-    ap.add_argument("--round", default="r02")
+    ap.add_argument("--round", default="r03")
     ap.add_argument("--precision", default="f16x3")
     ap.add_argument("--rays-per-call", type=int, default=0)
     a = ap.parse_args()
@@ -79,8 +79,23 @@ def main():
             "bytes_per_launch": byts, "kernel": k, "kernel_src_sha16": bench.kernel_source_digest(),
             "source": f"profiles/{a.round}/pmc_{tag}.json (separate rocprofv3 --pmc passes of `bench.py --config {a.config}`; (2*FETCH_SIZE + WRITE_SIZE) KiB; "
                       "L2-miss bytes: Infinity-Cache hits included)"}
+        # the two small kernels of the north_star's "sampling + integration" clause, from the same passes: measured L2-miss bytes and,
+        # for the sampler (VALU-bound: two erff and NV projections per candidate), the VALU-busy fraction
+        # (SQ_ACTIVE_INST_VALU counts quad-cycles: x4 / 1024 SIMDs, over GRBM_GUI_ACTIVE / 8 XCDs -- MI355X_MICROARCH.md)
+        small = {}
+        for name, key in (("sampler", "sampler_kernel"), ("composite", "composite_kernel")):
+            ks_ = [kk for kk in res if key in kk and "FETCH_SIZE" in res[kk] and "WRITE_SIZE" in res[kk]]
+            if ks_:
+                r_ = res[max(ks_, key=lambda n: res[n]["FETCH_SIZE"])]
+                small[name] = {"bytes_per_launch": (2 * r_["FETCH_SIZE"] + r_["WRITE_SIZE"]) * 1024}
+                if "SQ_ACTIVE_INST_VALU" in r_ and r_.get("GRBM_GUI_ACTIVE"):
+                    small[name]["valu_busy_frac"] = r_["SQ_ACTIVE_INST_VALU"] * 4 / 1024 / (r_["GRBM_GUI_ACTIVE"] / 8)
+        if small:
+            t[f"{a.config}:{a.precision}:{a.rays_per_call}:sampling_integration"] = dict(
+                small, kernel_src_sha16=bench.small_kernel_source_digest(),
+                source=f"profiles/{a.round}/pmc_{tag}.json (same passes; (2*FETCH_SIZE + WRITE_SIZE) KiB per launch)")
         tj.write_text(json.dumps(t, indent=1, sort_keys=True))
-        print("traffic", k, f"{byts / 1e9:.1f} GB per launch")
+        print("traffic", k, f"{byts / 1e9:.1f} GB per launch", {n: f"{v['bytes_per_launch'] / 1e9:.3f} GB" for n, v in small.items()})
         if "SQ_VALU_MFMA_BUSY_CYCLES" in res[k] and "GRBM_GUI_ACTIVE" in res[k]:
             busy = res[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (res[k]["GRBM_GUI_ACTIVE"] / 8)
             print(f"MFMA busy: {100 * busy:.1f} % of active cycles (per SIMD)")
