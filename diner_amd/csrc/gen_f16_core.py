@@ -254,8 +254,15 @@ class Block16(Block):
     Weight stream of a wave: ONE sequence of half-steps, 4 KiB each: [tf2][hi/lo][lane][8 halfs], lane = 16 kq + r holds
     W[feature 16 (2j + tf2) + r][k = 32 kstep + 8 kq ..+7].  nkb1 / nkb2 count k-steps."""
 
-    def __init__(self, name, acc_base, nks1, nks2, D, region1_off=65536, zero_init=False):
+    def __init__(self, name, acc_base, nks1, nks2, D, region1_off=65536, zero_init=False, convert_tail=False):
         assert D == 2 and nks1 > 0
+        # convert_tail: the layer's result is needed ONLY as the next layer's operand (net of a residual block: relu -> fp16 hi/lo
+        # split -> LDS).  The relu + split then happens IN PLACE in the layer's last k-step, tile by tile behind the tile's last product
+        # (two tiles later: far beyond the MFMA write -> VALU read wait states), in the shadow of the remaining MFMAs, instead of in the
+        # wave's next S phase, which is on the layer schedule's critical path.  Afterwards registers 0..3 of a tile hold
+        # lo(v0,v1) | hi(v0,v1) | lo(v2,v3) | hi(v2,v3) as packed fp16 pairs; the glue only stores them (store_converted).
+        self.convert_tail = convert_tail
+        self.converting = False
         self.name, self.base, self.nkb1, self.nkb2, self.D = name, acc_base, nks1, nks2, D
         self.region1_off = region1_off
         # zero_init: the accumulators need no initialisation by the caller -- the first product of every accumulator takes the inline
@@ -296,7 +303,21 @@ class Block16(Block):
             c = "0" if self.first_step and (wpart, fpart) == prods[0] else a     # zero_init: the accumulator's first product of the layer
             self.e(f"v_mfma_f32_16x16x32_f16 {a}, {ring(j, tf2, wpart)}, {self.fr(tp, fpart)}, {c}")
 
+    def convert(self, tf, tp):
+        """relu (keeps every NaN, like torch.relu and relu_split4<SAFE>) + hi/lo split of accumulator tile (tf, tp), in place"""
+        r = CAP + self.base + 4 * (4 * tf + tp)
+        for i in range(4):
+            self.e(f"v_cmp_ngt_f32_e64 %[m{i}], 0, v{r + i}")
+        for i in range(4):
+            self.e(f"v_cndmask_b32_e64 v{r + i}, 0, v{r + i}, %[m{i}]")
+        for a, b in ((r, r + 1), (r + 2, r + 3)):
+            self.e(f"v_cvt_pk_f16_f32 %[cva], v{a}, v{b}")
+            self.e(f"v_fma_mixlo_f16 v{a}, %[cva], -1.0, v{a} op_sel_hi:[1,0,0]")                       # lo16 of v_a := f16(v_a - hi_a); the rest of v_a stays
+            self.e(f"v_fma_mixhi_f16 v{a}, %[cva], -1.0, v{b} op_sel:[1,0,0] op_sel_hi:[1,0,0]")       # hi16 of v_a := f16(v_b - hi_b)
+            self.e(f"v_mov_b32 v{b}, %[cva]")
+
     def body(self, tail, switch):
+        done = []                                                     # (tf, tp) of the tiles whose last product has been issued
         for j in range(2):
             self.loads((j + 1) % 2)                                   # the next half-step's weights into the slot just used up
             if switch and j == 0:
@@ -310,6 +331,16 @@ class Block16(Block):
                 self.mfmas16(j, tp)
                 if j == 1 and not tail:
                     self.frag_read(tp)                                # rolling reload: needed again 18 MFMAs from here
+                if self.converting:                                   # the layer's last k-step: convert the tile that finished two tiles ago
+                    for tf2 in range(2):
+                        done.append((2 * j + tf2, tp))
+                    while len(done) > 2:
+                        self.convert(*done.pop(0))
+        if self.converting:
+            self.e("s_nop 15")                                        # the last two tiles: MFMA write -> VALU read wait states
+            self.e("s_nop 7")
+            for t in done:
+                self.convert(*t)
 
     def half(self, nks, region, last_half):
         self.e(f"v_add_u32 %[ab], {self.region1_off * region}, %[ab0]")
@@ -325,7 +356,9 @@ class Block16(Block):
             self.e("s_sub_u32 %[cnt], %[cnt], 1")
             self.e("s_cmp_lg_u32 %[cnt], 0")
             self.e(f"s_cbranch_scc1 {lbl}")
+        self.converting = self.convert_tail and last_half
         self.body(tail=True, switch=last_half)
+        self.converting = False
         self.first_step = False
 
 
@@ -340,6 +373,9 @@ def asm_body(lines):
 def cxx(block):
     lines = block.emit()
     frag_ops = ", ".join(f'[f{b}{i}] "=&v"(f{b}{i})' for b in range(2) for i in range(4))
+    cv = getattr(block, "convert_tail", False)
+    cv_decl = "    unsigned cva; unsigned long long m0, m1, m2, m3;\n" if cv else ""
+    cv_outs = ', [cva] "=&v"(cva), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)' if cv else ""
     return f"""
 // {block.name}: accumulators v[{CAP + block.base}:{CAP + block.base + 63}], {block.nkb1} + {block.nkb2} k-blocks, ring depth {block.D}
 // w0/w1: this wave's weight streams (feature tile 0/1) of THIS layer; nw0/nw1: of the layer executed next
@@ -347,10 +383,10 @@ __device__ __forceinline__ void {block.name}(uint64_t w0, uint64_t w1, uint64_t 
 {{
     h8 f00, f01, f02, f03, f10, f11, f12, f13;
     unsigned ab, voff, cnt;
-{flow_decl()}
+{cv_decl}{flow_decl()}
     asm volatile(
 {asm_body(lines)}
-        : {frag_ops}, [ab] "=&v"(ab), [voff] "=&v"(voff), [cnt] "=&s"(cnt), [w0] "+s"(w0), [w1] "+s"(w1){flow_outs()}{"".join(f', [tk{i}] "=&s"(st.t[{i}])' for i in range(6)) if STAMPS else ""}
+        : {frag_ops}, [ab] "=&v"(ab), [voff] "=&v"(voff), [cnt] "=&s"(cnt), [w0] "+s"(w0), [w1] "+s"(w1){flow_outs()}{cv_outs}{"".join(f', [tk{i}] "=&s"(st.t[{i}])' for i in range(6)) if STAMPS else ""}
         : [nw0] "s"(nw0), [nw1] "s"(nw1), [loff] "v"(loff), [ab0] "v"(ab0){flow_ins()}
         : "memory", "scc", {clobbers(block.D)});
 }}
@@ -576,6 +612,8 @@ def main():
                f"namespace {ns} {{\nstruct Stamps {{ unsigned long long t[6]; }};\n"]
         out.append(cxx(B_("layer_x_full", X_OFF, NK, NK, D)))
         out.append(cxx(B_("layer_net_full", NET_OFF, NK, NK, D)))
+        if SHAPE == 16:
+            out.append(cxx(B_("layer_net_full_cv", NET_OFF, NK, NK, D, convert_tail=True)))
         out.append(cxx(B_("layer_x_in", X_OFF, NKI, NKI, D, region1_off=8192)))
         if SHAPE == 16:
             out.append(cxx(B_("layer_x_in0", X_OFF, NKI, NKI, D, region1_off=8192, zero_init=True)))
@@ -594,6 +632,8 @@ constexpr int F16_X = {CAP + X_OFF}, F16_NET = {CAP + NET_OFF};   // first regis
     out.append(prologue(D))
     out.append(cxx(B_("layer_x_full", X_OFF, NK, NK, D)))
     out.append(cxx(B_("layer_net_full", NET_OFF, NK, NK, D)))
+    if SHAPE == 16:   # net = W0 relu(x) + b0 whose only reader is fc_1's operand: relu + split in the block's last k-step (convert_tail)
+        out.append(cxx(B_("layer_net_full_cv", NET_OFF, NK, NK, D, convert_tail=True)))
     # lin_in: 64 inputs = 4 k-blocks; waves 0-3 write unit-rows 0-3 (k < 32), waves 4-7 unit-rows 4-7 (8 KiB further)
     if D == 2:   # (the ring-4 build is a probe-only variant: tools/chain_probe.hip)
         out.append(cxx(B_("layer_x_in", X_OFF, NKI, NKI, D, region1_off=8192)))

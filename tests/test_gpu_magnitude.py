@@ -169,11 +169,14 @@ from synthetic.model_stub import model_from_scene
 dev = torch.device("cuda:0")
 sc, w, rays = _case(%s, 1.0, 0.0)
 m = model_from_scene(sc, w, device=dev)
+sc0, w0, rays0 = _case(1.0, 1.0, 0.0)
+m0 = model_from_scene(sc0, w0, device=dev)          # a healthy model for the calls before the last
 r = NeRFRendererDGS(n_samples=16, n_depth_candidates=64, n_gaussian=4)
-assert rays.shape[1] <= r.finite_sync_rays      # a small chunk: the deferred path
+assert rays.shape[1] <= r.finite_sync_rays      # small chunks: the deferred path
 with torch.no_grad():
     for i in range(3):
-        o = r(m, T(rays, dev))                  # the LAST call of the program; nobody calls check_finite()
+        r(m0, T(rays0, dev))
+    o = r(m, T(rays, dev))                      # the LAST call of the program; nobody calls check_finite()
 print("frames rendered", flush=True)
 """
 

@@ -1,5 +1,6 @@
 """A/B of libdiner_hip.so variants on ONE box: for each library given ("main" = the in-tree build), time the point/MLP kernel on
-half a cfg3 frame (131072 rays), interleaved rounds, one process per measurement."""
+half a cfg3 frame (131072 rays), interleaved rounds, one process per measurement.  A variant may carry environment switches:
+`main@DINER_F16_NO_VIT=1` = the in-tree library with that variable set."""
 import os, subprocess, sys
 libs = sys.argv[1:]
 code = r'''
@@ -32,8 +33,12 @@ print("RESULT min %.2f ms (frame-equivalent %.1f ms)" % (min(ts), 2 * min(ts)), 
 for rnd in range(2):
     for lib in libs:
         env = dict(os.environ)
-        if lib != "main":
-            env["DINER_LIB_PATH"] = lib
+        path, *sets = lib.split("@")
+        for kv in sets:
+            k, v = kv.split("=", 1)
+            env[k] = v
+        if path != "main":
+            env["DINER_LIB_PATH"] = path
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
         line = [l for l in p.stdout.splitlines() if l.startswith("RESULT")]
         print(rnd, lib, line[0] if line else p.stderr[-400:], flush=True)
