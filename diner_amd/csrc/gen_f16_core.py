@@ -254,8 +254,13 @@ class Block16(Block):
     Weight stream of a wave: ONE sequence of half-steps, 4 KiB each: [tf2][hi/lo][lane][8 halfs], lane = 16 kq + r holds
     W[feature 16 (2j + tf2) + r][k = 32 kstep + 8 kq ..+7].  nkb1 / nkb2 count k-steps."""
 
-    def __init__(self, name, acc_base, nks1, nks2, D, region1_off=65536, zero_init=False, convert_tail=False):
+    def __init__(self, name, acc_base, nks1, nks2, D, region1_off=65536, zero_init=False, convert_tail=False, bias_init=False):
         assert D == 2 and nks1 > 0
+        # bias_init: acc := bias + W a without an initialisation pass -- the first product of every accumulator takes the bias as its C
+        # operand: 4 register quads %[bq0..3] (features 64w + 16tf + 4q ..+3: the same for the 4 point tiles of a lane), read from LDS
+        # by the caller.  The first k-step is peeled off the loop for it.
+        self.bias_init = bias_init
+        assert not (bias_init and zero_init)
         # convert_tail: the layer's result is needed ONLY as the next layer's operand (net of a residual block: relu -> fp16 hi/lo
         # split -> LDS).  The relu + split then happens IN PLACE in the layer's last k-step, tile by tile behind the tile's last product
         # (two tiles later: far beyond the MFMA write -> VALU read wait states), in the shadow of the remaining MFMAs, instead of in the
@@ -300,7 +305,9 @@ class Block16(Block):
         pairs = [(p, tf2) for tf2 in range(2) for p in prods] if ORDER == "acc" else [(p, tf2) for p in prods for tf2 in range(2)]
         for (wpart, fpart), tf2 in pairs:                             # --order=acc: the 3 products of an accumulator back to back
             a = self.acc16(2 * j + tf2, tp)
-            c = "0" if self.first_step and (wpart, fpart) == prods[0] else a     # zero_init: the accumulator's first product of the layer
+            c = a
+            if self.first_step and (wpart, fpart) == prods[0]:        # the accumulator's first product of the layer
+                c = "0" if self.zero_init else f"%[bq{2 * j + tf2}]"  # zero_init / bias_init
             self.e(f"v_mfma_f32_16x16x32_f16 {a}, {ring(j, tf2, wpart)}, {self.fr(tp, fpart)}, {c}")
 
     def convert(self, tf, tp):
@@ -347,6 +354,13 @@ class Block16(Block):
         for tp in range(4):
             self.frag_read(tp)                                        # the half's first k-step, behind the barrier / arrival wait
         self.first_step = self.zero_init and region == 0              # (nks == 1 there: the tail body below is the layer's first k-step)
+        peel = self.bias_init and region == 0
+        if peel:                                                      # the layer's first k-step, peeled: C = bias
+            assert nks > 2
+            self.first_step = True
+            self.body(tail=False, switch=False)
+            self.first_step = False
+            nks -= 1
         if nks > 1:
             lbl = f"L{self.nlabel}_%="
             self.nlabel += 1
@@ -376,10 +390,13 @@ def cxx(block):
     cv = getattr(block, "convert_tail", False)
     cv_decl = "    unsigned cva; unsigned long long m0, m1, m2, m3;\n" if cv else ""
     cv_outs = ', [cva] "=&v"(cva), [m0] "=&s"(m0), [m1] "=&s"(m1), [m2] "=&s"(m2), [m3] "=&s"(m3)' if cv else ""
+    bi = getattr(block, "bias_init", False)
+    bi_args = ", const f32x4 &bq0, const f32x4 &bq1, const f32x4 &bq2, const f32x4 &bq3" if bi else ""
+    bi_ins = ', [bq0] "v"(bq0), [bq1] "v"(bq1), [bq2] "v"(bq2), [bq3] "v"(bq3)' if bi else ""
     return f"""
 // {block.name}: accumulators v[{CAP + block.base}:{CAP + block.base + 63}], {block.nkb1} + {block.nkb2} k-blocks, ring depth {block.D}
 // w0/w1: this wave's weight streams (feature tile 0/1) of THIS layer; nw0/nw1: of the layer executed next
-__device__ __forceinline__ void {block.name}(uint64_t w0, uint64_t w1, uint64_t nw0, uint64_t nw1, unsigned loff, unsigned ab0, const Sync &sy{", Stamps &st" if STAMPS else ""})
+__device__ __forceinline__ void {block.name}(uint64_t w0, uint64_t w1, uint64_t nw0, uint64_t nw1, unsigned loff, unsigned ab0, const Sync &sy{bi_args}{", Stamps &st" if STAMPS else ""})
 {{
     h8 f00, f01, f02, f03, f10, f11, f12, f13;
     unsigned ab, voff, cnt;
@@ -387,7 +404,7 @@ __device__ __forceinline__ void {block.name}(uint64_t w0, uint64_t w1, uint64_t 
     asm volatile(
 {asm_body(lines)}
         : {frag_ops}, [ab] "=&v"(ab), [voff] "=&v"(voff), [cnt] "=&s"(cnt), [w0] "+s"(w0), [w1] "+s"(w1){flow_outs()}{cv_outs}{"".join(f', [tk{i}] "=&s"(st.t[{i}])' for i in range(6)) if STAMPS else ""}
-        : [nw0] "s"(nw0), [nw1] "s"(nw1), [loff] "v"(loff), [ab0] "v"(ab0){flow_ins()}
+        : [nw0] "s"(nw0), [nw1] "s"(nw1), [loff] "v"(loff), [ab0] "v"(ab0){flow_ins()}{bi_ins}
         : "memory", "scc", {clobbers(block.D)});
 }}
 """
@@ -614,6 +631,7 @@ def main():
         out.append(cxx(B_("layer_net_full", NET_OFF, NK, NK, D)))
         if SHAPE == 16:
             out.append(cxx(B_("layer_net_full_cv", NET_OFF, NK, NK, D, convert_tail=True)))
+            out.append(cxx(B_("layer_net_full_b", NET_OFF, NK, NK, D, bias_init=True)))
         out.append(cxx(B_("layer_x_in", X_OFF, NKI, NKI, D, region1_off=8192)))
         if SHAPE == 16:
             out.append(cxx(B_("layer_x_in0", X_OFF, NKI, NKI, D, region1_off=8192, zero_init=True)))
@@ -634,6 +652,7 @@ constexpr int F16_X = {CAP + X_OFF}, F16_NET = {CAP + NET_OFF};   // first regis
     out.append(cxx(B_("layer_net_full", NET_OFF, NK, NK, D)))
     if SHAPE == 16:   # net = W0 relu(x) + b0 whose only reader is fc_1's operand: relu + split in the block's last k-step (convert_tail)
         out.append(cxx(B_("layer_net_full_cv", NET_OFF, NK, NK, D, convert_tail=True)))
+        out.append(cxx(B_("layer_net_full_b", NET_OFF, NK, NK, D, bias_init=True)))     # net := b0 + W0 relu(x), the bias as the first C operand
     # lin_in: 64 inputs = 4 k-blocks; waves 0-3 write unit-rows 0-3 (k < 32), waves 4-7 unit-rows 4-7 (8 KiB further)
     if D == 2:   # (the ring-4 build is a probe-only variant: tools/chain_probe.hip)
         out.append(cxx(B_("layer_x_in", X_OFF, NKI, NKI, D, region1_off=8192)))
