@@ -383,6 +383,50 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs g)
     tile_store<AK>(T[0][0], T[0][1], ra[0], oka[0], fa, sa, tid);
     tile_store<!BNC>(T[0][2], T[0][3], rb[0], okb[0], fb, sb, tid);
     __syncthreads();
+// DINER_DW_INTERLEAVE (default on): the step is ONE basic block -- loads of tile t+2 unconditional (past the end they re-read clamped
+// addresses with all pieces invalid), the MFMAs of tile t, then split + store of tile t+1 into the other LDS buffer (past the end: zeros
+// into a buffer nobody reads) -- and the scheduler is told to deal the step's 8 global loads and the split's VALU work BETWEEN the 24
+// MFMAs (sched_group_barrier, as in the panel kernel): before, the three phases ran one after the other in every wave (in-kernel stamps
+// of a 4.3 k-cycle step: 1.0 k issuing the loads, 1.05 k MFMA, 2.0 k waiting for tile t+1 + split + store).
+#ifndef DINER_DW_INTERLEAVE
+#define DINER_DW_INTERLEAVE 1
+#endif
+#if DINER_DW_INTERLEAVE
+#define DINER_GEMM_STEP(SL)                                                                                      \
+    {                                                                                                            \
+        const int64_t k2 = kbeg + (t + 2) * BKH;                                                                 \
+        oka[SL] = tile_load<AK>(ra[SL], g.A, g.sam, g.sak, m0, g.M, k2, kend, tid);                              \
+        okb[SL] = tile_load<!BNC>(rb[SL], g.B, g.sbn, g.sbk, n0, g.N, k2, kend, tid);                            \
+        _Pragma("unroll") for (int ks = 0; ks < BKH / 16; ++ks) {                                                \
+            const int u = ks * 2 + h;                                                                            \
+            h8 ah[2], al[2], bh[2], bl[2];                                                                       \
+            _Pragma("unroll") for (int q = 0; q < 2; ++q) {                                                      \
+                const int oa = unit(u, wm + 32 * q + r), ob = unit(u, wn + 32 * q + r);                          \
+                ah[q] = T[SL][0][oa]; al[q] = T[SL][1][oa];                                                      \
+                bh[q] = T[SL][2][ob]; bl[q] = T[SL][3][ob];                                                      \
+            }                                                                                                    \
+            _Pragma("unroll") for (int ta = 0; ta < 2; ++ta)                                                     \
+                _Pragma("unroll") for (int tb = 0; tb < 2; ++tb) {                                               \
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ta], bh[tb], acc[ta][tb], 0, 0, 0);  \
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ta], bl[tb], acc[ta][tb], 0, 0, 0);  \
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ta], bh[tb], acc[ta][tb], 0, 0, 0);  \
+                }                                                                                                \
+        }                                                                                                        \
+        tile_store<AK>(T[1 - SL][0], T[1 - SL][1], ra[1 - SL], oka[1 - SL], fa, sa, tid);                        \
+        tile_store<!BNC>(T[1 - SL][2], T[1 - SL][3], rb[1 - SL], okb[1 - SL], fb, sb, tid);                      \
+        /* sched_group_barrier masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write, 0x002 VALU */  \
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);  /* fragments of the first k-step */                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 24; ++i_) {                                                      \
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+            if (i_ < 16 && (i_ & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);                     \
+            if (i_ < 8) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                       \
+            __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);                                                   \
+            if (i_ >= 8 && (i_ & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);                     \
+        }                                                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                                       \
+        __syncthreads();                                                                                         \
+    }
+#else
 #define DINER_GEMM_STEP(SL)                                                                                      \
     {                                                                                                            \
         const int64_t k2 = kbeg + (t + 2) * BKH;                                                                 \
@@ -413,6 +457,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs g)
         }                                                                                                        \
         __syncthreads();                                                                                         \
     }
+#endif
     for (int64_t t = 0; t < steps; ++t) {
         DINER_GEMM_STEP(0)
         if (++t >= steps) break;

@@ -71,6 +71,7 @@ class _FiniteGuard:
     def __init__(self):
         self.status = None   # device int32 word
         self.pending = []    # [(event, pinned host word)] oldest first
+        self.free = []       # examined (event, word) pairs, reused by after_launch
         self.precision = "f16x3"
 
     def word(self, dev):
@@ -95,15 +96,18 @@ class _FiniteGuard:
             ev, host = self.pending.pop(0)
             ev.synchronize()
             bad |= bool(int(host[0]) & 1)
+            if len(self.free) < 8:
+                self.free.append((ev, host))
         if bad:
             self.pending = []
             self.status.zero_()
             raise RuntimeError(self.message())
 
     def after_launch(self, dev):
-        host = torch.empty(1, dtype=torch.int32, pin_memory=True)
+        # pinned host words and events are recycled (a pinned allocation per call costs tens of microseconds of host time:
+        # 64 calls per 512 x 512 image in the reference's 4096-ray chunks)
+        ev, host = self.free.pop() if self.free else (torch.cuda.Event(), torch.empty(1, dtype=torch.int32, pin_memory=True))
         host.copy_(self.status, non_blocking=True)
-        ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream(dev))
         self.pending.append((ev, host))
 
