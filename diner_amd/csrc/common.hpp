@@ -22,7 +22,7 @@ int check_launch(const char *what);
 // persistent grids, and the raised dynamic-LDS limit of a kernel (hipFuncSetAttribute acts on the current device's copy of the function).
 // Both are cached per device ordinal (api.hip); thread-safe (atomics; a race only repeats an idempotent call).
 int device_cus();                                                    // CUs of the current device (256 on MI355X)
-enum LdsSlot { LDS_SLOT_F16_LINZ = 0, LDS_SLOT_F16_LATENT = 2, LDS_SLOT_F16_TRACE = 4, LDS_SLOT_TRAIN_CORE0 = 6, LDS_SLOT_COUNT = LDS_SLOT_TRAIN_CORE0 + 4 };   // (the f16 slots come in pairs: view-sequential / views-in-tile)
+enum LdsSlot { LDS_SLOT_F16_LINZ = 0, LDS_SLOT_F16_LATENT = 2, LDS_SLOT_F16_TRACE = 4, LDS_SLOT_TRAIN_CORE0 = 6, LDS_SLOT_DW512 = 10, LDS_SLOT_COUNT = 12 };   // (the f16 slots come in pairs: view-sequential / views-in-tile)
 int ensure_dynamic_lds(const void *kernel, int bytes, int slot);    // DINER_OK, or DINER_E_LAUNCH with the error set
 
 // --------------------------------------------------------------------------------------------

@@ -467,6 +467,206 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(GemmArgs g)
     epilogue<!AK, BNC>(g, acc, m0, n0, wm, wn, lane, ia * ib);
 }
 
+// ---- the weight-gradient GEMM of a 512 x 512 layer: dW[i][j] += sum_m dY[m][i] * relu?(X[m][j])  (reference: autograd of nn.Linear in
+//      src/models/resnetfc.py:61-69 as trained by DINER.calc_losses src/models/diner.py:217-290) -- round 3.
+// Both operands stream from HBM along the CONTRACTION index (rows m: 655,360 per training step) and are split into fp16 hi / lo in
+// the kernel, so the split's VALU work per loaded element is what the generic 128 x 128 kernel above spent its time on (2.0 k of a
+// 4.3 k-cycle step).  Here ONE workgroup of 8 waves owns a 256 x 256 output tile (the whole 512 x 512 result is 4 tiles; split-K over
+// 64 row chunks fills the 256 CUs): every loaded element feeds twice the MFMAs, a wave owns 128 x 64 (8 accumulator tiles, 128
+// registers), the LDS images of a 32-row step are 64 KiB, double-buffered in the CU's 160 KiB.  Staging is the generic kernel's: a
+// 4 (k) x 4 (l) micro-tile per thread, transposed in registers, stored in slot16 order (conflict-free ds_write_b64), fragments are
+// single conflict-free ds_read_b128; the accumulator rows / columns come out in slot order (undone in the atomic epilogue).
+// The 4 tiles of a row chunk run on ONE XCD (they read the same two operand slices: one HBM fetch, three L2 hits).
+#ifndef DINER_DW512
+#define DINER_DW512 1      // 0: the generic split-K kernel for the weight gradients too (A/B knob)
+#endif
+namespace dw512 {
+using f16g::h8;
+using f16g::put4;
+using f16g::scale_of;
+constexpr int TM = 256, KS = 32, NT = 512;
+constexpr int PLANE = (KS / 8) * TM;                   // 16-byte units of one fp16 plane of one operand: 1024 = 16 KiB
+constexpr int LDS_BYTES = 2 * 4 * PLANE * 16;          // [2 buffers][A hi, A lo, B hi, B lo] = 128 KiB
+
+struct Args {
+    const float *dY, *X;
+    float *dW;
+    int64_t M, ldy, ldx, ldw;      // contraction length (rows), row strides
+    int relu_x;
+    const unsigned int *amax_y;    // power-of-two scaling of dY from its measured maximum (or exp_y), X by exp_x: see GemmArgs
+    int exp_y, exp_x;
+    int64_t k_chunk;               // rows per workgroup (multiple of 32)
+    int nchunks;                   // multiple of 8
+};
+
+__device__ __forceinline__ int unit(int u, int row) { return u * TM + (row ^ (4 * u)); }
+
+// one operand tile = 32 (k) x 256 (l) fp32 = 2048 float4, four per thread: thread = (k-quad kq4 of 8, l-quad lq4 of 64), float4 along l
+__device__ __forceinline__ void thread_of(int tid, int &kq4, int &lq4)
+{
+    kq4 = (tid & 3) | ((tid >> 4) & 4);
+    lq4 = ((tid >> 2) & 15) | ((tid >> 3) & 16) | ((tid >> 3) & 32);
+}
+// generic form (the chunk's first tile and its ragged end): rows clamped, a validity bit per piece
+__device__ __forceinline__ unsigned load_tile(f32x4 (&v)[4], const float *__restrict__ base, int64_t ld, int l0, int64_t k0, int64_t k_end, int tid)
+{
+    int kq4, lq4;
+    thread_of(tid, kq4, lq4);
+    unsigned ok = 0;   // unconditional loads from clamped rows (a load under a branch makes hipcc wait per load)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int64_t k = k0 + kq4 * 4 + i;
+        ok |= (unsigned)(k < k_end) << i;
+        v[i] = *(const f32x4 *)(base + (k < k_end ? k : k_end - 1) * ld + l0 + lq4 * 4);
+    }
+    return ok;
+}
+// MASK: pieces whose bit in `ok` is clear are zeros (ragged end only); RELU: the floor at 0 that keeps NaN (split4_pk<true>)
+template <bool MASK, bool RELU>
+__device__ __forceinline__ void store_tile(h8 *Thi, h8 *Tlo, const f32x4 (&v)[4], unsigned ok, float sc, int tid)
+{
+    int kq4, lq4;
+    thread_of(tid, kq4, lq4);
+    f32x4 x[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[i][j] = (!MASK || ((ok >> i) & 1u)) ? v[i][j] : 0.0f;
+    // row l + c of the tile goes to LDS slot slot16(l + c) = (l & ~15) | 4c | (lq4 & 3): see f16g::tile_store<false>
+    const int kq = kq4 * 4, sl = ((lq4 * 4) & ~15) | (lq4 & 3);
+    _Float16 *ph = (_Float16 *)Thi + unit(kq >> 3, sl) * 8 + (kq & 4), *pl = (_Float16 *)Tlo + unit(kq >> 3, sl) * 8 + (kq & 4);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {   // slots sl + 4c: sl's bits 2, 3 are clear, and the unit's swizzle (row ^ 4u) only touches those: + 4c units... see below
+        f16g::u32x2 hi, lo;
+        unsigned a, b, cc, d;
+        f16g::split4_pk<RELU>(x[0][c], x[1][c], x[2][c], x[3][c], sc, a, b, cc, d);
+        hi.x = a; hi.y = b; lo.x = cc; lo.y = d;
+        const int o = unit(kq >> 3, sl + 4 * c) * 8 + (kq & 4);
+        *(f16g::u32x2 *)((_Float16 *)Thi + o) = hi;
+        *(f16g::u32x2 *)((_Float16 *)Tlo + o) = lo;
+    }
+    (void)ph; (void)pl;
+}
+
+template <bool RELU_X>
+__global__ __launch_bounds__(512) void dw512_kernel(Args g)
+{
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    h8 *T = (h8 *)lds_raw;                                           // T[(buf * 4 + plane) * PLANE + unit]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // the 4 output tiles of a chunk on one XCD (workgroups are dealt to the XCDs round-robin by launch order)
+    const int lin = blockIdx.x, xcd = lin % 8, jj = lin / 8;
+    const int chunk = (jj / 4) * 8 + xcd, tile = jj % 4;
+    const int i0 = (tile >> 1) * TM, j0 = (tile & 1) * TM;
+    const int64_t kbeg = (int64_t)chunk * g.k_chunk;
+    const int64_t kend = kbeg + g.k_chunk < g.M ? kbeg + g.k_chunk : g.M;
+    if (kbeg >= kend) return;
+    const int wm = (wave >> 2) * 128, wn = (wave & 3) * 64;          // the wave's 128 x 64 of the tile
+    float sa, ia, sb, ib;
+    scale_of(g.amax_y, g.exp_y, sa, ia);
+    scale_of(nullptr, g.exp_x, sb, ib);
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.0f;
+    f32x4 ra[4], rb[4];
+    const int r = lane & 31, h = lane >> 5;
+    const int64_t steps = (kend - kbeg + KS - 1) / KS, full = (kend - kbeg) / KS;   // tiles; tiles without a ragged end
+    int kq4, lq4;
+    thread_of(tid, kq4, lq4);
+    // this thread's 4 x 4 micro-tile of the NEXT tile to load: row kbeg + KS (t + 1) + 4 kq4, columns 4 lq4 .. + 3 of the operand's slice
+    const float *pa = g.dY + (kbeg + kq4 * 4) * g.ldy + i0 + lq4 * 4, *pb = g.X + (kbeg + kq4 * 4) * g.ldx + j0 + lq4 * 4;
+    const int64_t sta = KS * g.ldy, stb = KS * g.ldx;
+
+    unsigned oka = load_tile(ra, g.dY, g.ldy, i0, kbeg, kend, tid);
+    unsigned okb = load_tile(rb, g.X, g.ldx, j0, kbeg, kend, tid);
+    store_tile<true, false>(T + 0 * PLANE, T + 1 * PLANE, ra, oka, sa, tid);
+    store_tile<true, RELU_X>(T + 2 * PLANE, T + 3 * PLANE, rb, okb, sb, tid);
+    __syncthreads();
+
+    // the 48 MFMAs of a tile out of LDS buffer `sl`: the wave's 128 x 64, two 16-deep halves
+    auto multiply = [&](int sl) {
+        const h8 *Ahi = T + (sl * 4 + 0) * PLANE, *Alo = T + (sl * 4 + 1) * PLANE, *Bhi = T + (sl * 4 + 2) * PLANE, *Blo = T + (sl * 4 + 3) * PLANE;
+#pragma unroll
+        for (int ks = 0; ks < KS / 16; ++ks) {
+            const int u = ks * 2 + h;
+            h8 bh[2], bl[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) { const int ob = unit(u, wn + 32 * q + r); bh[q] = Bhi[ob]; bl[q] = Blo[ob]; }
+#pragma unroll
+            for (int ta = 0; ta < 4; ++ta) {
+                const int oa = unit(u, wm + 32 * ta + r);
+                const h8 ah = Ahi[oa], al = Alo[oa];
+#pragma unroll
+                for (int tb = 0; tb < 2; ++tb) {
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[tb], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[tb], acc[ta][tb], 0, 0, 0);
+                    acc[ta][tb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[tb], acc[ta][tb], 0, 0, 0);
+                }
+            }
+        }
+    };
+
+    int64_t t = 0;
+    // ---- hot loop: steps whose NEXT tile is a full one.  ONE basic block: the 8 loads of tile t + 1 (plain pointer increments, no
+    //      clamps, no masks), the 48 MFMAs of tile t out of buffer t & 1, split + store of tile t + 1 into the other buffer; the
+    //      scheduler deals fragment reads, the split's VALU work and the stores between the MFMAs (sched_group_barrier)
+    for (; t + 1 < full; ++t) {
+        const int sl = (int)(t & 1);
+        pa += sta; pb += stb;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { ra[i] = *(const f32x4 *)(pa + i * g.ldy); rb[i] = *(const f32x4 *)(pb + i * g.ldx); }
+        multiply(sl);
+        h8 *N = T + ((1 - sl) * 4) * PLANE;
+        store_tile<false, false>(N, N + PLANE, ra, 0xFu, sa, tid);
+        store_tile<false, RELU_X>(N + 2 * PLANE, N + 3 * PLANE, rb, 0xFu, sb, tid);
+        /* sched_group_barrier masks: 0x008 MFMA, 0x020 VMEM read, 0x100 DS read, 0x200 DS write, 0x002 VALU */
+        __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);   // the step's 8 global loads first: they are consumed at its end
+        __builtin_amdgcn_sched_group_barrier(0x100, 6, 0);   // B fragments + the first A pair
+#pragma unroll
+        for (int i_ = 0; i_ < 48; ++i_) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (i_ % 6 == 0 && i_ < 42) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            if (i_ >= 12) __builtin_amdgcn_sched_group_barrier(0x002, 5, 0);
+            if (i_ >= 12 && (i_ & 1) == 0) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    }
+    // ---- the chunk's last steps (at most two): the next tile is ragged or does not exist
+    for (; t < steps; ++t) {
+        const int sl = (int)(t & 1);
+        const int64_t k1 = kbeg + (t + 1) * KS;
+        oka = load_tile(ra, g.dY, g.ldy, i0, k1, kend, tid);
+        okb = load_tile(rb, g.X, g.ldx, j0, k1, kend, tid);
+        multiply(sl);
+        h8 *N = T + ((1 - sl) * 4) * PLANE;
+        store_tile<true, false>(N, N + PLANE, ra, oka, sa, tid);
+        store_tile<true, RELU_X>(N + 2 * PLANE, N + 3 * PLANE, rb, okb, sb, tid);
+        __syncthreads();
+    }
+    // epilogue: C layout of the 32x32 accumulators: col = lane & 31, row = (i & 3) + 8 (i >> 2) + 4 (lane >> 5); rows and columns are
+    // in slot order (both operands were staged by the transposing store)
+    const float unscale = ia * ib;
+#pragma unroll
+    for (int tb = 0; tb < 2; ++tb) {
+        const int j = j0 + slot16(wn + tb * 32 + (lane & 31));
+#pragma unroll
+        for (int ta = 0; ta < 4; ++ta) {
+            const int rb0 = wm + ta * 32 + 4 * (lane >> 5);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int row = i0 + slot16(rb0 + (i & 3) + 8 * (i >> 2));
+                atomicAdd(g.dW + (int64_t)row * g.ldw + j, acc[ta][tb][i] * unscale);
+            }
+        }
+    }
+}
+}  // namespace dw512
+
 // max |x| over n floats as a bit pattern (non-negative floats order like unsigned integers); *out zeroed by the launcher
 __global__ __launch_bounds__(256) void amax_kernel(const float *__restrict__ x, int64_t n, unsigned int *__restrict__ out)
 {
@@ -750,6 +950,19 @@ int launch_gemm(const GemmArgs &g, int precision, hipStream_t st)
     if (!bnc && g.sbk != 1) { set_error("gemm: B must be contiguous along k or n"); return DINER_E_INVALID; }
     if (precision == DINER_PRECISION_F16X3) {
         if (g.k_chunk > 0 && kc % f16g::BKH) { set_error("gemm: k_chunk must be a multiple of 32 in f16x3 mode"); return DINER_E_INVALID; }
+        // the weight gradient of a 512 x 512 layer (dW += dY^T relu?(X), atomic split-K, both operands row-major along the contraction):
+        // the dedicated 256 x 256-tile kernel
+        if (DINER_DW512 && !ak && bnc && g.atomic && g.M == f16g::dw512::NT && g.N == f16g::dw512::NT && !g.bias && !g.S && !g.relu_a && !g.amax_b &&
+            g.K >= 64 * 32 * 4 && g.sak % 4 == 0 && g.sbk % 4 == 0 && g.ldc % 1 == 0) {
+            f16g::dw512::Args d{g.A, g.B, g.C, g.K, g.sak, g.sbk, g.ldc, g.relu_b, g.amax_a, g.exp_a, g.exp_b, 0, 64};
+            d.k_chunk = ((g.K + d.nchunks - 1) / d.nchunks + 31) / 32 * 32;
+            const void *fn = g.relu_b ? (const void *)f16g::dw512::dw512_kernel<true> : (const void *)f16g::dw512::dw512_kernel<false>;
+            if (const int rc = ensure_dynamic_lds(fn, f16g::dw512::LDS_BYTES, LDS_SLOT_DW512 + (g.relu_b ? 1 : 0))) return rc;
+            void *kargs[] = {(void *)&d};
+            if (hipLaunchKernel(fn, dim3(4 * d.nchunks), dim3(512), kargs, f16g::dw512::LDS_BYTES, st) != hipSuccess)
+                return check_launch("train::dw512_kernel(launch)");
+            return check_launch("train::dw512_kernel");
+        }
         if (ak && bnc) hipLaunchKernelGGL((f16g::gemm_f16x3_kernel<true, true>), grid, dim3(256), 0, st, a);
         else if (ak && !bnc) hipLaunchKernelGGL((f16g::gemm_f16x3_kernel<true, false>), grid, dim3(256), 0, st, a);
         else if (!ak && bnc) hipLaunchKernelGGL((f16g::gemm_f16x3_kernel<false, true>), grid, dim3(256), 0, st, a);
