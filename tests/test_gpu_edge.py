@@ -82,12 +82,14 @@ def test_unsupported_candidate_count_raises(dev):
         run_gpu(sc, w, rays, 8, 4096, 2, None, dev)
 
 
+# NV = 3: the view-sequential form of the f16x3 point kernel; NV = 4, 8: its views-in-tile form (one / two view groups per sub-tile)
+@pytest.mark.parametrize("NV", [3, 4, 8])
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
-def test_batch_of_two_scenes(dev, precision):
+def test_batch_of_two_scenes(dev, precision, NV):
     """SB = 2 (the reference trains with batches of scenes, pixelnerf.py:68): every scene of the batch must
     equal its own single-scene render."""
-    a, w = make(seed=40)
-    b, _ = make(seed=41, bg_sigma_zero=True)
+    a, w = make(seed=40, NV=NV)
+    b, _ = make(seed=41, NV=NV, bg_sigma_zero=True)
     both = copy.copy(a)
     for name in ("poses", "focal", "c", "depths", "depths_std", "normals", "latent"):
         setattr(both, name, np.concatenate([getattr(a, name), getattr(b, name)], 0))
@@ -104,10 +106,12 @@ def test_batch_of_two_scenes(dev, precision):
     agree(rgb[1], run_oracle(b, w, rb[:, :n], K, NC, G, nb)["rgb"])
 
 
+@pytest.mark.parametrize("NV", [3, 4, 8])
 @pytest.mark.parametrize("precision", ["fp32", "f16x3"])
-def test_ragged_tail_and_tiny_inputs(dev, precision):
-    """Point counts that are not a multiple of the 64-point tile, down to a single ray."""
-    sc, w = make(seed=50)
+def test_ragged_tail_and_tiny_inputs(dev, precision, NV):
+    """Point counts that are not a multiple of the 64-point tile (nor of the 16-point sub-tile of the views-in-tile form), down to
+    a single ray."""
+    sc, w = make(seed=50, NV=NV)
     K, NC, G = 40, 200, 15  # reference defaults for K and G (configs/train_diner_facescape.yaml:61-66)
     for n_rays in (1, 7, 33):
         rays = sc.target_rays()[:, 100:100 + n_rays]
@@ -157,6 +161,51 @@ def test_rays_that_miss_every_surface(dev):
     zd = orc.sample_depthguided(rays, zc, K, G, noise[1])
     assert not zd.any(), "scene construction: these rays should have no likelihood"
     np.testing.assert_array_equal(z, orc.fill_up(rays, zd, noise[2]))
+
+
+@pytest.mark.parametrize("linz", [True, False])
+def test_views_in_tile_equals_view_sequential(dev, linz, monkeypatch):
+    """The two forms of the f16x3 point kernel on the same inputs (NV = 4, 8; lin_z maps and per-point lin_z GEMMs): the views-in-tile
+    form sums the views in the reference's order like the view-sequential one, so the two agree to the last bits of fp32 (not bit for
+    bit: NV = 8 parks a partial sum per group of 4 views).  The sequential form is selected per PROCESS (DINER_F16_NO_VIT is read once), so
+    it runs in a child process."""
+    import subprocess, sys, tempfile
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    code = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from tests.test_gpu_edge import make, T
+from diner_amd import NeRFRendererDGS
+from synthetic.model_stub import model_from_scene
+dev = torch.device("cuda:0")
+outs = {}
+for NV in (4, 8):
+    sc, w = make(seed=60 + NV, NV=NV)
+    rays = sc.target_rays()[:, ::5]
+    K = 24
+    z = np.sort(np.random.RandomState(NV).uniform(sc.near, sc.far, (1, rays.shape[1], K)).astype(np.float32), -1)
+    m = model_from_scene(sc, w, device=dev)
+    r = NeRFRendererDGS(n_samples=K, n_depth_candidates=64, n_gaussian=4)
+    r.linz_maps = %s
+    with torch.no_grad():
+        outs[str(NV)] = r.render_points(m, T(rays, dev), T(z, dev)).cpu().numpy()
+np.savez(sys.argv[1], **outs)
+""" % (str(root), "True" if linz else "False")
+    res = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, env in (("vit", {}), ("seq", {"DINER_F16_NO_VIT": "1"})):
+            import os
+            e = dict(os.environ); e.update(env)
+            out = str(Path(td) / (name + ".npz"))
+            p = subprocess.run([sys.executable, "-c", code, out], capture_output=True, text=True, timeout=600, cwd=str(root), env=e)
+            assert p.returncode == 0, p.stderr[-2000:]
+            res[name] = dict(np.load(out))
+    for k in res["vit"]:
+        a, b = res["vit"][k], res["seq"][k]
+        assert np.isfinite(a).all() and np.isfinite(b).all()
+        d = np.abs(a - b)
+        assert float(d[..., :3].max()) <= 2e-6 and float((d[..., 3] / np.maximum(1.0, np.abs(b[..., 3]))).max()) <= 2e-6, (k, float(d.max()))
 
 
 def test_chunk_invariance(dev):
