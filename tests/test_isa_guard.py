@@ -28,9 +28,10 @@ def _compile(tmp_path_factory, *defines):
 
 @pytest.fixture(scope="module", params=["product", "diag"])
 def isa(request, tmp_path_factory):
-    """the product build (2 instantiations) and the tools build with the TRACE instantiation (-DDINER_F16_DIAG: 3)"""
+    """the product build (4 instantiations: lin_z maps or per-point lin_z GEMMs x view-sequential or views-in-tile) and the tools build
+    with the TRACE instantiations (-DDINER_F16_DIAG: + 2)"""
     text = _compile(tmp_path_factory, *(["-DDINER_F16_DIAG"] if request.param == "diag" else []))
-    return text, (3 if request.param == "diag" else 2)
+    return text, (6 if request.param == "diag" else 4)
 
 
 def _cap():
@@ -59,7 +60,7 @@ def test_compiler_stays_out_of_the_core_registers(isa):
     cap = _cap()
     lines = isa.split("\n")
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN5diner5f16x321points_mlp_f16_kernelILb[01]ELb[01]E\S+:", l)]
-    assert len(starts) == n_inst, "expected the instantiations <lin_z maps>, <per-point lin_z GEMMs> (+ the <trace> one in the tools build)"
+    assert len(starts) == n_inst, "expected <lin_z maps | per-point lin_z GEMMs> x <view-sequential | views-in-tile> (+ the two <trace> ones in the tools build)"
     for s0 in starts:
         end = next(i for i in range(s0, len(lines)) if "s_endpgm" in lines[i])
         in_asm, core_mfma, core_loads, stmt = False, 0, 0, []
