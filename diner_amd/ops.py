@@ -39,14 +39,23 @@ def build(force: bool = False) -> Path:
 STAMP = LIB.with_suffix(".stamp")
 
 
+_digest_cache = {}
+
+
 def _deps_digest() -> str:
     """sha256 over what the extension is built from and links against: torch_ops.cpp, the ABI header, libdiner_hip.so itself
-    (contents, not mtimes: the snapshot that carries the build to the GPU box need not preserve times)."""
+    (contents, not mtimes: the snapshot that carries the build to the GPU box need not preserve times).  Hashed once per process and
+    state of the files (every renderer constructor asks)."""
     import hashlib
-    h = hashlib.sha256()
-    for p in (SRC, SRC.parents[2] / "include" / "diner_hip.h", _lib.LIB_PATH):
-        h.update(p.read_bytes() if p.exists() else b"<missing>")
-    return h.hexdigest()
+    deps = (SRC, SRC.parents[2] / "include" / "diner_hip.h", _lib.LIB_PATH)
+    key = tuple((str(p), p.stat().st_mtime_ns, p.stat().st_size) if p.exists() else (str(p), 0, 0) for p in deps)
+    if key not in _digest_cache:
+        h = hashlib.sha256()
+        for p in deps:
+            h.update(p.read_bytes() if p.exists() else b"<missing>")
+        _digest_cache.clear()
+        _digest_cache[key] = h.hexdigest()
+    return _digest_cache[key]
 
 
 def stale() -> bool:
