@@ -47,6 +47,7 @@ PRIO_B = 0                                      # --priob=N: GEMM priority of wa
 WBITS = ""                                      # --wbits=nt|sc0|...: cache-policy bits of the weight-stream loads
 STAMPS = False                                  # --stamps: diagnostic layer blocks only (namespace of --ns), 6 s_memtime stamps each (tools/trace_f16.py)
 FLOW = False                                    # --flow: arrival counters in LDS instead of the three workgroup barriers per layer
+SLEEP = 1                                       # --sleep=N: s_sleep between two polls of an arrival counter (N x 64 clocks)
 X_OFF, NET_OFF, RING_OFF = 0, 64, 128           # relative to CAP
 POISON_OFF = 24                                 # byte offset (from the arrival counters) of the workgroup's poison word, see Block.wait
 
@@ -142,7 +143,7 @@ class Block:
         self.e("s_sub_u32 %[spin], %[spin], 1")
         self.e("s_cmp_eq_u32 %[spin], 0")
         self.e(f"s_cbranch_scc1 T{lbl}")
-        self.e("s_sleep 1")
+        self.e(f"s_sleep {SLEEP}")
         self.e(f"s_branch {lbl}")
         # timed out (a protocol error; unreachable in a correct build): the wave goes on with operand rows nobody vouches for, so the
         # WHOLE tile must come out non-finite, not just this wave's share: set the workgroup's poison word (LDS, %[ctr] + POISON_OFF;
@@ -574,7 +575,7 @@ __device__ __forceinline__ bool flow_wait(unsigned addr, unsigned target)
 {{
     unsigned pv, cnt, spin;
     asm volatile(
-{asm_body([f"s_mov_b32 %[spin], {SPIN_LIMIT}", "W_%=:", "ds_read_b32 %[pv], %[a]", "s_waitcnt lgkmcnt(0)", "v_readfirstlane_b32 %[cnt], %[pv]", "s_cmp_ge_u32 %[cnt], %[tgt]", "s_cbranch_scc1 D_%=", "s_sub_u32 %[spin], %[spin], 1", "s_cmp_eq_u32 %[spin], 0", "s_cbranch_scc1 D_%=", "s_sleep 1", "s_branch W_%=", "D_%=:"])}
+{asm_body([f"s_mov_b32 %[spin], {SPIN_LIMIT}", "W_%=:", "ds_read_b32 %[pv], %[a]", "s_waitcnt lgkmcnt(0)", "v_readfirstlane_b32 %[cnt], %[pv]", "s_cmp_ge_u32 %[cnt], %[tgt]", "s_cbranch_scc1 D_%=", "s_sub_u32 %[spin], %[spin], 1", "s_cmp_eq_u32 %[spin], 0", "s_cbranch_scc1 D_%=", f"s_sleep {SLEEP}", "s_branch W_%=", "D_%=:"])}
         : [pv] "=&v"(pv), [cnt] "=&s"(cnt), [spin] "=&s"(spin) : [a] "v"(addr), [tgt] "s"(target) : "memory", "scc");
     return spin != 0;
 }}
@@ -610,7 +611,8 @@ def main():
     global CAP, PRIO
     CAP = 256 - 128 - 16 * D
     PRIO = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--prio=')), 0)
-    global FLOW, STAMPS, WBITS, PRIO_B, SHAPE, ORDER, PRODS
+    global FLOW, STAMPS, WBITS, PRIO_B, SHAPE, ORDER, PRODS, SLEEP
+    SLEEP = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--sleep=')), 1)
     PRODS = next((a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--prods=')), "small")
     ORDER = next((a.split('=', 1)[1] for a in sys.argv[1:] if a.startswith('--order=')), "prod")
     SHAPE = next((int(a.split('=', 1)[1]) for a in sys.argv[1:] if a.startswith('--shape=')), 32)

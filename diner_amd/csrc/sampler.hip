@@ -383,7 +383,8 @@ int launch_sampler(const DinerScene &s, const float *rays, const DinerTargetCam 
     if (NC <= 64 * 4) DINER_LAUNCH_SAMPLER(4);
     else if (NC <= 64 * 16) DINER_LAUNCH_SAMPLER(16);
     else if (NC <= 64 * 32) DINER_LAUNCH_SAMPLER(32);
-    else { set_error("sampler: n_candidates=%d > 2048 unsupported", NC); return DINER_E_UNSUPPORTED; }
+    else if (NC <= 64 * 64) DINER_LAUNCH_SAMPLER(64);   // (4096 candidates: 64 per lane stay in registers; beyond that they would spill)
+    else { set_error("sampler: n_candidates=%d > 4096 unsupported", NC); return DINER_E_UNSUPPORTED; }
 #undef DINER_LAUNCH_SAMPLER
     return check_launch("sampler_kernel");
 }

@@ -62,7 +62,7 @@ def test_number_of_views(dev, NV):
     agree(out.fine.rgb.cpu().numpy()[0], ref["rgb"])
 
 
-@pytest.mark.parametrize("NC,K,G", [(64, 8, 2), (250, 16, 4), (1000, 256, 96), (1500, 40, 15), (2048, 32, 8)])
+@pytest.mark.parametrize("NC,K,G", [(64, 8, 2), (250, 16, 4), (1000, 256, 96), (1500, 40, 15), (2048, 32, 8), (4096, 24, 6)])
 def test_candidate_and_sample_counts(dev, NC, K, G):
     """NC selects the sampler's candidates-per-lane variant (4 / 16 / 32); K = 256 is cfg5's sample count."""
     sc, w = make(seed=30)
@@ -79,7 +79,7 @@ def test_unsupported_candidate_count_raises(dev):
     sc, w = make(seed=31)
     rays = sc.target_rays()[:, :4]
     with pytest.raises(NotImplementedError):
-        run_gpu(sc, w, rays, 8, 4096, 2, None, dev)
+        run_gpu(sc, w, rays, 8, 4097, 2, None, dev)
 
 
 # NV = 3: the view-sequential form of the f16x3 point kernel; NV = 4, 8: its views-in-tile form (one / two view groups per sub-tile)
