@@ -174,7 +174,7 @@ __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_num_vgpr(F16_VGP
     sy.one = 1;
     sy.lay = 0;
     sy.half = wave >> 2;
-    if (tid < 8) ((volatile unsigned *)(lds + LDS_CTR))[tid] = 0;
+    if (tid < 8) ((__attribute__((address_space(3))) volatile unsigned *)(lds + LDS_CTR))[tid] = 0;   // (typed: a generic volatile access becomes a FLAT instruction)
     ring_prologue(wst(0), wst(1), loff);
     if ((int64_t)blockIdx.x < (g.M + TILE_M - 1) / TILE_M) prefetch_a(g, blockIdx.x, wave, c, h);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (once: the first tile's A; later tiles are covered by the layer block's waits)
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(NWAVES * 64) __attribute__((amdgpu_num_vgpr(F16_VGP
             const int rq = lane >> 4, q4 = lane & 15, col = wave * 64 + 4 * q4;
             // the core's poison word (a flow wait that gave up: never in a correct build): the tile's C becomes NaN, amax_out inf -- a
             // silently wrong gradient is the one thing this kernel must not produce
-            const bool poisoned = F16_FLOW && *(volatile unsigned *)(lds + LDS_CTR + F16_POISON_OFF) != 0;
+            const bool poisoned = F16_FLOW && *(__attribute__((address_space(3))) volatile unsigned *)(lds + LDS_CTR + F16_POISON_OFF) != 0;
             if (poisoned) amax = __builtin_inff();
 #pragma unroll 1
             for (int i0 = 0; i0 < 16; i0 += 4) {

@@ -87,6 +87,22 @@ def test_compiler_stays_out_of_the_core_registers(isa):
         assert core_mfma >= 400 and core_loads >= 100
 
 
+def test_no_flat_instructions(isa, tmp_path_factory):
+    """The kernels that run the generated core issue no FLAT instruction: a FLAT op goes down the LDS and the memory path at once and
+    counts in lgkmcnt as well as vmcnt -- both of which the core's counted waits and the arrival protocol rely on.  hipcc emits FLAT
+    for every pointer it cannot type (one that passed through an empty asm; any volatile access): with the view-sum slab on flat_load /
+    flat_store a 4-wave geometry build produced rare wrong samples on the GPU (tools/dbg/g1_race.py), so those accesses carry explicit
+    address spaces (points_mlp_f16.hip: gload4 / gstore4 / lds_vu32; train_core.hip) and this test keeps it that way."""
+    text, _ = isa
+    flat = re.findall(r"^\s+(flat_\w+)", text, re.M)
+    assert not flat, sorted(set(flat))
+    asm = tmp_path_factory.mktemp("isa_tc") / "train_core.s"
+    subprocess.run([HIPCC, "-O3", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm", "-S", "--cuda-device-only",
+                    "-o", str(asm), str(CSRC / "train_core.hip")], check=True, capture_output=True, timeout=900)
+    flat = re.findall(r"^\s+(flat_\w+)", asm.read_text(), re.M)
+    assert not flat, sorted(set(flat))
+
+
 def test_register_budget(isa):
     """2 waves per SIMD: 256 registers per lane in all, none of them AGPRs."""
     isa, n_inst = isa

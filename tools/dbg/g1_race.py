@@ -21,7 +21,8 @@ for name, prec in (("g1_nv2_k64_dtu", "f16x3-gemm"), ("g3_nv3_k40_wide", "f16x3-
             o = r.render_points(m, T(g.rays, dev), T(g["z_fill"], dev)[None]).cpu().numpy()[0]
             d = np.abs(o[..., :3] - g["rgbsigma"][..., :3])
             bad = np.argwhere(d.max(-1) > 1e-4)
-            res.append("%d%s" % (len(bad), ("@" + ",".join("%d.%d" % tuple(b) for b in bad[:3])) if len(bad) else ""))
+            nan = int((~np.isfinite(o)).any(-1).sum())   # (a poisoned tile: every sample NaN)
+            res.append("%d%s%s" % (len(bad), ("@" + ",".join("%d.%d[%s]" % (b[0], b[1], "/".join("%.0e" % x for x in (o[b[0], b[1]] - g["rgbsigma"][b[0], b[1]]))) for b in bad[:3])) if len(bad) else "", ("!nan%d" % nan) if nan else ""))
 print("RES", " ".join(res))
 '''
 for lib in sys.argv[1:]:
