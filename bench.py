@@ -156,12 +156,22 @@ def host_cores():
 KERNEL_SOURCES = ("points_mlp_f16.hip", "f16_core16.inc", "gen_f16_core.py", "points_mlp.hip", "common.hpp", "Makefile")
 
 
+def _code_bytes(path: Path) -> bytes:
+    """a source file as the digests see it: C++ sources without their `//` comments, trailing blanks and empty lines (no string literal
+    of these files contains `//`), so that a comment-only edit does not orphan a recorded profile; everything else byte for byte"""
+    data = path.read_bytes()
+    if path.suffix not in (".hip", ".hpp", ".inc", ".h"):
+        return data
+    lines = (l.split("//", 1)[0].rstrip() for l in data.decode().splitlines())
+    return "\n".join(l for l in lines if l).encode()
+
+
 def kernel_source_digest() -> str:
-    """sha256 (16 hex) over the sources the dominant kernel is built from: ties a recorded PMC figure to a kernel version
-    (.git does not travel to the GPU box, the sources do)."""
+    """sha256 (16 hex) over the sources the dominant kernel is built from (code only, see _code_bytes): ties a recorded PMC figure to a
+    kernel version (.git does not travel to the GPU box, the sources do)."""
     h = hashlib.sha256()
     for name in KERNEL_SOURCES:
-        h.update((ROOT / "diner_amd" / "csrc" / name).read_bytes())
+        h.update(_code_bytes(ROOT / "diner_amd" / "csrc" / name))
     return h.hexdigest()[:16]
 
 
@@ -172,7 +182,7 @@ def small_kernel_source_digest() -> str:
     """the same for sampler_kernel / composite_kernel (the `sampling_integration` object)"""
     h = hashlib.sha256()
     for name in SMALL_KERNEL_SOURCES:
-        h.update((ROOT / "diner_amd" / "csrc" / name).read_bytes())
+        h.update(_code_bytes(ROOT / "diner_amd" / "csrc" / name))
     return h.hexdigest()[:16]
 
 

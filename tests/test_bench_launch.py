@@ -106,3 +106,18 @@ def test_traffic_figure_is_tied_to_the_kernel_sources(monkeypatch):
     assert val is None and src.startswith("stale")
     val, src = bench.traffic_record(argparse.Namespace(config="tiny", precision="f16x3", rays_per_call=0))
     assert val is None
+
+
+def test_source_digest_sees_code_not_comments(tmp_path):
+    """the digest that ties a profile to a kernel version ignores `//` comments and blank lines of the C++ sources (a comment-only edit
+    must not orphan a recorded profile) and nothing else"""
+    import importlib
+    sys.path.insert(0, str(ROOT))
+    bench = importlib.import_module("bench")
+    a, b, c, py = tmp_path / "a.hip", tmp_path / "b.hip", tmp_path / "c.hip", tmp_path / "g.py"
+    a.write_text("// header\nint f() { return 1; }   // one\n\n")
+    b.write_text("int f() { return 1; }\n// another comment\n")
+    c.write_text("int f() { return 2; }\n")
+    py.write_text("x = 1  # // not C++\n")
+    assert bench._code_bytes(a) == bench._code_bytes(b) != bench._code_bytes(c)
+    assert bench._code_bytes(py) == py.read_bytes()

@@ -90,11 +90,11 @@ def test_compiler_stays_out_of_the_core_registers(isa):
 def test_no_flat_instructions(isa):
     """No kernel of the library issues a FLAT instruction.  hipcc emits FLAT for every pointer it cannot type (one that passed through
     an empty asm; any volatile access).  A FLAT op goes down the LDS path and the memory path at once and counts in lgkmcnt as well as
-    vmcnt -- and its store data is not safe behind the 2 wait states hipcc leaves before a VALU write of the data registers: with the
-    view-sum slab on flat_store_dwordx4 (two stores, s_nop 0, then the glue's next accumulator read lands in the first store's data
-    register) a 4-wave geometry build returned rare wrong samples on the GPU -- 14 of 16 processes of tools/dbg/g1_race.py, 0 of 16 with
-    s_nop 3 behind each store, 0 of 72 with global_store (tools/dbg/build_flat_repro.sh rebuilds the failing form).
-    Those accesses carry explicit address spaces now (points_mlp_f16.hip: gload4 / gstore4 / lds_vu32 / g_u32; train_core.hip)."""
+    vmcnt.  With the view-sum slab on flat_store_dwordx4 a 4-wave geometry build returned rare wrong samples on the GPU -- 13-14 of 16
+    processes of tools/dbg/g1_race.py with the stores flat, 0 of 16 with only the loads flat, 0 of 72 with global_store (DESIGN.md 4.1
+    item 11: the mechanism is not established -- tools/flat_store_probe.hip does not reproduce it in isolation;
+    tools/dbg/build_flat_repro.sh rebuilds the failing form).  Those accesses carry explicit address spaces now (points_mlp_f16.hip:
+    gload4 / gstore4 / lds_vu32 / g_u32; train_core.hip)."""
     text, _ = isa
     flat = re.findall(r"^\s+(flat_\w+)", text, re.M)
     assert not flat, sorted(set(flat))
