@@ -192,6 +192,12 @@ class Block:
             self.e(f"s_cbranch_scc1 {lbl}")
         self.body(tail=True, switch=last_half)
 
+    def both_first(self):
+        """lin_in (both its halves in physical region 0, region1_off != 65536): the kernel is free to deal its 8 unit-rows to the 8 waves in
+        any order (points_mlp_f16.hip: the rows that need the depth fetch go to waves 0-3, which have slack), so the block waits for BOTH
+        arrival counters before its first half instead of one per half.  The block is two k-steps long: nothing is lost."""
+        return FLOW and self.region1_off != 65536 and self.nkb2 > 0
+
     def emit(self):
         D = self.D
         step = 4096 if isinstance(self, Block16) else 2048
@@ -208,6 +214,8 @@ class Block:
             self.stamp(0)
             self.signal("half")                                       # my operand rows are written: SA or SB += 1
             self.wait("ctr", 0, 4)                                    # G1 reads region 0: all of waves 0-3 have written theirs (SA >= 4 lay)
+            if self.both_first():
+                self.wait("ctr", 4, 4)                                # lin_in: ANY wave may have written ANY of its 8 unit-rows: both groups first
             self.stamp(1)
         else:
             self.e("s_waitcnt lgkmcnt(0)")                            # this wave's operand stores (its S phase) have landed
@@ -216,7 +224,7 @@ class Block:
         if FLOW:
             self.stamp(2)
             self.signal(8)                                            # G1 += 1: my reads of region 0 are over
-            if self.nkb2:
+            if self.nkb2 and not self.both_first():
                 self.wait("ctr", 4, 4)                                # G2 reads region 1: SB >= 4 lay
             self.stamp(3)
         else:
