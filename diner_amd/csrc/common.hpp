@@ -71,6 +71,27 @@ __device__ __forceinline__ void project(const View &v, float iw, float ih, float
     w = w / ih * 2.0f - 1.0f;
 }
 
+// sin() of the positional encodings.  The argument is the reference's fp32 value (one fma, positional_encoding.py:45-49); its sine comes
+// from the hardware's v_sin_f32 (sin(2 pi x) of an argument in revolutions) behind a compensated reduction: r1 = RN(a * C_HI),
+// r2 = the part of a / 2pi that r1 lost (exact by fma) + a * C_LO, sin(2 pi (fract(r1) + r2)) -- accurate for every finite a.  Measured
+// over the encodings' range (tools/sin_probe.hip, 1.7e7 arguments up to 705 rad): max |error| 4.2e-7 against 6.8e-8 for sinf -- below
+// the 2^-22 x 16 granularity of the fp16 hi/lo operand split the value goes through next -- for 6 instructions instead of the ~90 of
+// the inlined sinf (with its Payne-Hanek path), 48 times per point and view.  Used by the default (f16x3) inference kernel
+// (points_mlp_f16.hip) and by the training path's point_inputs_kernel (train.hip); the exact-fp32 inference kernel (points_mlp.hip)
+// keeps sinf.  -DDINER_PE_LIBM=1: sinf everywhere.
+#ifndef DINER_PE_LIBM
+#define DINER_PE_LIBM 0
+#endif
+__device__ __forceinline__ float pe_sin(float a)
+{
+    if (DINER_PE_LIBM) return sinf(a);
+    const float C_HI = 0.15915494f;                                             // fp32(1 / 2pi)
+    const float C_LO = (float)(0.15915494309189535 - (double)0.15915494f);
+    const float r1 = a * C_HI;
+    const float r2 = __builtin_fmaf(a, C_HI, -r1) + a * C_LO;
+    return __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(r1) + r2);
+}
+
 // grid_sample(align_corners=False) un-normalisation, contracted as ATen compiles it
 __device__ __forceinline__ float unnorm(float u, float half_size) { return __builtin_fmaf(u + 1.0f, half_size, -0.5f); }
 

@@ -1022,11 +1022,11 @@ __global__ __launch_bounds__(64) void point_inputs_kernel(DinerScene s, const fl
         float val;
         if (e < 3) val = e == 0 ? px : e == 1 ? py : pz;
         else if (e < 39) { const int j = (e - 3) / 3, i = (e - 3) % 3;
-            val = sinf(__builtin_fmaf(i == 0 ? px : i == 1 ? py : pz, s.freq_factor * (float)(1 << (j >> 1)), (j & 1) ? half_pi : 0.0f)); }
+            val = pe_sin(__builtin_fmaf(i == 0 ? px : i == 1 ? py : pz, s.freq_factor * (float)(1 << (j >> 1)), (j & 1) ? half_pi : 0.0f)); }
         else if (e < 42) val = e == 39 ? dcx : e == 40 ? dcy : dcz;
         else if (e == 42) val = delta;
         else if (e < 55) { const int j = e - 43;
-            val = sinf(__builtin_fmaf(delta, s.freq_factor * (float)(1 << (j >> 1)), (j & 1) ? half_pi : 0.0f)); }
+            val = pe_sin(__builtin_fmaf(delta, s.freq_factor * (float)(1 << (j >> 1)), (j & 1) ? half_pi : 0.0f)); }
         else val = 0.0f;
         in56[row * 56 + e] = val;
     }
