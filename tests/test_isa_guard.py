@@ -93,7 +93,7 @@ def test_no_flat_instructions(isa):
     vmcnt.  With the view-sum slab on flat_store_dwordx4 a 4-wave geometry build returned rare wrong samples on the GPU -- 13-14 of 16
     processes of tools/dbg/g1_race.py with the stores flat, 0 of 16 with only the loads flat, 0 of 72 with global_store (DESIGN.md 4.1
     item 11: the mechanism is not established -- tools/flat_store_probe.hip does not reproduce it in isolation;
-    tools/dbg/build_flat_repro.sh rebuilds the failing form).  Those accesses carry explicit address spaces now (points_mlp_f16.hip:
+    tools/dbg/build_flat_repro.sh rebuilds the failing form at commit cbb8e8d).  Those accesses carry explicit address spaces now (points_mlp_f16.hip:
     gload4 / gstore4 / lds_vu32 / g_u32; train_core.hip)."""
     text, _ = isa
     flat = re.findall(r"^\s+(flat_\w+)", text, re.M)

@@ -3,7 +3,8 @@
 # (hipcc then emits flat_load / flat_store) + 4-wave geometry + DINER_BIAS_C.  The product source carries no knob for it: this script
 # compiles a patched temporary copy.   tools/dbg/build_flat_repro.sh [stores|loads|both|stores_nop]   -> tools/dbg/libdiner_hip_flat_<which>.so
 # (stores_nop: the flat stores each followed by s_nop 3 -- more wait states before anything can overwrite their data registers)
-# then:  REPS=16 python tools/dbg/g1_race.py tools/dbg/libdiner_hip_flat_both.so        (on the GPU box: about 15 of 16 processes hit)
+# then:  REPS=16 python tools/dbg/g1_race.py tools/dbg/libdiner_hip_flat_both.so        (13-15 of 16 processes hit at commit cbb8e8d; 0 of 16 on the round-3
+# final tree: the failure also needs the register allocation and timing of that commit -- check it out to reproduce)
 set -e
 which=${1:-both}
 cd "$(dirname "$0")/../../diner_amd/csrc"
