@@ -12,7 +12,8 @@ def parse(path):
     for l in open(path):
         m = re.match(r"\[f16 trace\] wave(\d+):(.*)", l)
         if m:
-            waves[int(m.group(1))] = [(int(a), int(b)) for a, b in (t.split(":") for t in m.group(2).split())]
+            # stamps are relative to wave 0's first one, printed as unsigned 64-bit: a wave that started earlier shows a wrapped value
+            waves[int(m.group(1))] = [(int(a), int(b) - (1 << 64) if int(b) >= (1 << 63) else int(b)) for a, b in (t.split(":") for t in m.group(2).split())]
     if not waves:
         print("no trace lines"); return
     for w, ev in sorted(waves.items()):
